@@ -1,0 +1,126 @@
+/*
+ * gitcap.h - C ABI of libgitcap.so: MI355X (gfx950) native GIT-style video-caption inference.
+ *
+ * The reference (farazali7/real-time-video-captioning) has no FFI/plugin layer: its boundary is
+ * duck-typed Python methods on the model object.  Each entry point below names the reference
+ * call it stands behind (paths relative to the reference root), so a maintainer can bind it with
+ * ctypes (gitcap/model.py is that binding).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative gitcap_status; the message is read with
+ *     gitcap_last_error(h) (h may be NULL for errors raised by gitcap_create);
+ *   - no C++ exception crosses this boundary;
+ *   - the caller owns every input/output buffer (device memory unless stated otherwise);
+ *     the handle owns weights, KV cache and workspace;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and is
+ *     asynchronous; nothing here synchronises the device except gitcap_load_tensor/finalize;
+ *   - a handle is bound to one device and is not thread-safe.
+ */
+#ifndef GITCAP_H
+#define GITCAP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gitcap gitcap_t;
+
+typedef enum {
+    GITCAP_OK = 0,
+    GITCAP_ERR_ARG = -1,      /* bad argument / shape outside what the handle was created for */
+    GITCAP_ERR_STATE = -2,    /* call order violated (e.g. decode before prefill, weights missing) */
+    GITCAP_ERR_HIP = -3,      /* a HIP runtime call failed */
+    GITCAP_ERR_NOMEM = -4
+} gitcap_status;
+
+typedef enum { GITCAP_F32 = 0, GITCAP_BF16 = 1 } gitcap_dtype;
+
+/* greedy stop rules */
+typedef enum {
+    GITCAP_STOP_NEVER = 0,    /* always run max_len steps (fixed work; bench) */
+    GITCAP_STOP_ALL_SEP = 1   /* reference rule: stop when ALL rows emit SEP in the same step
+                                 (src/models/model.py:184); rows keep generating after their own SEP */
+} gitcap_stop;
+
+/* Hyper-parameters: src/models/model.py:681-718 (get_git_model) and
+ * data/teacher_configs/GIT_LARGE_MSRVTT/parameter.yaml:1-3.  Field order is mirrored by
+ * gitcap.config.CGitCapConfig. */
+typedef struct gitcap_config {
+    int32_t image_size, patch_size;
+    int32_t enc_width, enc_layers, enc_heads, enc_ffn;
+    int32_t dec_width, dec_layers, dec_heads, dec_ffn;
+    int32_t vocab_size, max_text_pos;
+    int32_t num_frames;            /* num_image_with_embedding; 0 = no temporal embedding */
+    int32_t cls_token_id, sep_token_id, pad_token_id;
+    float enc_ln_eps, dec_ln_eps, proj_ln_eps;
+    int32_t max_batch;             /* clips per call the workspace is sized for */
+    int32_t max_frames;            /* frames per clip */
+    int32_t max_text_len;          /* text positions per row (CLS + generated) */
+    int32_t max_beams;             /* >= 1 */
+} gitcap_config;
+
+/* Replaces: get_git_model(tokenizer, param)            src/models/model.py:681-718
+ *           GenerativeImageTextTeacher.__init__          src/models/model.py:726-745 */
+int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out);
+void gitcap_destroy(gitcap_t* h);
+const char* gitcap_last_error(const gitcap_t* h);
+
+/* Replaces: load_state_dict(self.model, ckpt)            src/models/model.py:736-738
+ * `name` is a canonical tensor name (gitcap/weights.py); `data` is HOST memory, fp32, row-major.
+ * The library converts GEMM weights to bf16 (round-to-nearest-even) and keeps tables, biases and
+ * LayerNorm parameters in fp32.  gitcap_finalize_weights fails if any tensor is missing. */
+int gitcap_load_tensor(gitcap_t* h, const char* name, const float* data,
+                       const int64_t* shape, int rank);
+int gitcap_finalize_weights(gitcap_t* h);
+
+/* Replaces: self.image_encoder(torch.stack(batch['image'])) + temporal add + cat(dim=1)
+ *                                                         src/models/model.py:378-382
+ *           the 'linearLn' visual projection              src/models/model.py:699
+ *           and the image half of self.textual(...)       src/models/model.py:412-418
+ * frames: device [B,F,3,H,W] fp32 NCHW (layout of src/utils/dataloader.py:60-82).
+ * visual_out (nullable): device fp32 [B, F*N, enc_width] = ln_post + temporal embedding
+ * (the `visual_features` the reference returns at model.py:424 / :460).
+ * Because image tokens never attend to text (GIT block mask) their decoder K/V are text
+ * independent: this call also runs the projected image tokens through the decoder layers and
+ * leaves their K/V in the handle (the exact KV cache every later text call reads). */
+int gitcap_encode(gitcap_t* h, const float* frames, int B, int F, float* visual_out, void* stream);
+
+/* Same as the second half of gitcap_encode, starting from caller-supplied visual features
+ * (device fp32 [B, S_img, enc_width]); lets forward_decoder(y, memory) honour `memory`. */
+int gitcap_set_visual(gitcap_t* h, const float* visual, int B, int S_img, void* stream);
+
+/* Replaces: self.textual(visual_features, caption_tokens)  src/models/model.py:412-418
+ *           scores = step(input_ids)                        src/models/model.py:519
+ * Runs text positions t0 .. t0+T-1 of `rows` rows through the decoder against the cached image
+ * K/V of clip (row / beams) and the row's own cached text K/V (text->image full, text->text
+ * causal), appending their K/V to the text cache.  Positions < t0 must have been run before.
+ * ids: device int64, token of row r / position t0+j at ids[r*ld_ids + j].
+ * logits_out (nullable): device fp32 [rows, T, vocab] when all_positions != 0 (teacher-forced
+ * logits of forward_output_logits, model.py:747-760), else [rows, vocab] for position t0+T-1.
+ * argmax_out (nullable): device int64, argmax of the last position's logits written to
+ * argmax_out[r*ld_argmax]. */
+int gitcap_text_forward(gitcap_t* h, const int64_t* ids, int ld_ids, int rows, int beams,
+                        int t0, int T, float* logits_out, int all_positions,
+                        int64_t* argmax_out, int ld_argmax, void* stream);
+
+/* Replaces: StudentCandidateV1.greedy_decode(src, max_len) src/models/model.py:156-187
+ *           as called by src/real_time_inference.py:58 and src/inference.py:51
+ * Encodes, prefills with CLS and runs max_len greedy steps entirely on the device.
+ * ids_out: device int64 [B, max_len+1] (column 0 = CLS).  steps_out: device int32[1] = number
+ * of generated columns that are valid under `stop` (the host truncates to 1+steps). */
+int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, int stop,
+                  int64_t* ids_out, int32_t* steps_out, void* stream);
+
+/* Beam reorder of the text part of the KV cache (what src/models/model.py:623-634 sketches):
+ * new row r takes the cached text K/V of old row src_rows[r]; image K/V are shared. */
+int gitcap_reorder_rows(gitcap_t* h, const int32_t* src_rows, int rows, int t_len, void* stream);
+/* Introspection used by tests and bench.py */
+int gitcap_workspace_bytes(const gitcap_t* h, int64_t* bytes);
+int gitcap_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GITCAP_H */

@@ -1,0 +1,238 @@
+"""CPU oracle for the GIT captioning hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module; the product path (real-time-video-captioning_amd/) never does.
+
+PARITY PINNING: the reference tree holds no golden vectors, fixtures or passing tests for this
+path and the arithmetic itself lives in the un-vendored, *unpinned*
+third-party package ``generativeimage2text`` (microsoft/GenerativeImage2Text, requirements.txt:19
+of the reference; call sites /root/reference/src/models/model.py:11-16, :682, :687).  So parity is
+UNPINNED BY THE REFERENCE.  The oracle is instead pinned against the only implementation of the
+same published model available offline: ``transformers.models.git`` (HF port of MS GIT, v5.15.0),
+through the fixtures in tests/golden/ produced by oracle/gen_golden_hf.py.
+
+What this file restates (plain torch fp32, no ``transformers`` import, no reference import):
+  * frame batching, temporal-embedding add and token concat   - model.py:372-382
+  * ``self.textual(visual_features, caption_tokens)``          - model.py:412-418
+  * model hyper-parameters                                     - model.py:681-700
+  * greedy stop semantics of the student API                   - model.py:156-187
+  * CLIP-ViT tower / linearLn projection / BERT-style decoder with the GIT block mask:
+    published GIT algorithm as ported in transformers/models/git/modeling_git.py
+    (:73-113 text embeddings, :116-197 attention, :229-290 layer, :343-423 vision embeddings,
+     :465-553 vision block, :591-626 tower, :689-699 projection, :796-884 model forward).
+
+``emulate_bf16=True`` reproduces the rounding points of the HIP path:
+GEMM operands (weights and the activations fed to a GEMM, incl. q/k/v, softmax probabilities
+and GELU outputs) are rounded to bf16, everything else (accumulators, residual stream,
+LayerNorm, softmax statistics, embeddings, logits) stays fp32.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as Fn
+
+
+def _r(x: torch.Tensor, on: bool) -> torch.Tensor:
+    """Round-to-nearest-even to bf16 and back to fp32 (identity when emulation is off)."""
+    return x.to(torch.bfloat16).to(torch.float32) if on else x
+
+
+class GitOracle:
+    def __init__(self, cfg, weights: Dict[str, np.ndarray], emulate_bf16: bool = False,
+                 threads: Optional[int] = None):
+        self.cfg = cfg
+        self.bf = bool(emulate_bf16)
+        if threads:
+            torch.set_num_threads(threads)
+        self.w: Dict[str, torch.Tensor] = {}
+        for k, v in weights.items():
+            t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).clone()
+            # GEMM weights are stored in bf16 on the device; tables/bias/LN stay fp32
+            if self.bf and t.ndim == 2 and k not in ("enc.pos", "temporal", "txt.word", "txt.pos"):
+                t = _r(t, True)
+            self.w[k] = t
+
+    # ------------------------------------------------------------------ primitives
+    def _lin(self, x, name):
+        """y = bf16(x) @ bf16(W)^T + b with fp32 accumulation."""
+        return Fn.linear(_r(x, self.bf), self.w[name + ".w"], self.w[name + ".b"])
+
+    def _ln(self, x, name, eps):
+        return Fn.layer_norm(x, (x.shape[-1],), self.w[name + ".w"], self.w[name + ".b"], eps)
+
+    def _attn(self, q, k, v, klimit: torch.Tensor):
+        """q [B,H,Tq,64], k/v [B,H,Tk,64] (already bf16-rounded when emulating);
+        klimit [Tq] = number of visible keys per query row."""
+        s = torch.matmul(q, k.transpose(-1, -2)) * (1.0 / math.sqrt(q.shape[-1]))
+        Tk = k.shape[-2]
+        vis = torch.arange(Tk)[None, :] < klimit[:, None]               # [Tq,Tk]
+        s = s.masked_fill(~vis, float("-inf"))
+        m = s.max(dim=-1, keepdim=True).values
+        p = torch.exp(s - m)
+        l = p.sum(dim=-1, keepdim=True)
+        o = torch.matmul(_r(p, self.bf), v) / l
+        return o
+
+    @staticmethod
+    def _heads(x, H):     # [B,T,H*64] -> [B,H,T,64]
+        B, T, _ = x.shape
+        return x.view(B, T, H, -1).transpose(1, 2)
+
+    @staticmethod
+    def _merge(x):        # [B,H,T,64] -> [B,T,H*64]
+        B, H, T, d = x.shape
+        return x.transpose(1, 2).reshape(B, T, H * d)
+
+    # ------------------------------------------------------------------ encoder (a2,a3)
+    def encode_frames(self, frames: torch.Tensor) -> torch.Tensor:
+        """frames [B,F,3,H,W] fp32 NCHW -> visual features [B, F*N, Dv]
+        (= ln_post output + temporal embedding, frames concatenated along tokens:
+        model.py:378-382)."""
+        cfg = self.cfg
+        B, F = frames.shape[:2]
+        p, g, Dv, H = cfg.patch_size, cfg.grid, cfg.enc_width, cfg.enc_heads
+        x = frames.reshape(B * F, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(B * F, g * g, 3 * p * p)
+        x = torch.matmul(_r(x.float(), self.bf), self.w["enc.patch_w"].t())        # conv k=stride=p, no bias
+        cls = self.w["enc.cls"].expand(B * F, 1, Dv)
+        x = torch.cat([cls, x], dim=1) + self.w["enc.pos"][None]
+        x = self._ln(x, "enc.ln_pre", cfg.enc_ln_eps)
+        N = x.shape[1]
+        full = torch.full((N,), N)
+        for i in range(cfg.enc_layers):
+            pre = f"enc.L{i}."
+            h = self._ln(x, pre + "ln1", cfg.enc_ln_eps)
+            qkv = _r(self._lin(h, pre + "qkv"), self.bf)
+            q, k, v = (self._heads(t, H) for t in qkv.split(Dv, dim=-1))
+            a = self._merge(self._attn(q, k, v, full))
+            x = x + self._lin(a, pre + "proj")
+            h = self._ln(x, pre + "ln2", cfg.enc_ln_eps)
+            h = self._lin(h, pre + "fc1")
+            h = h * torch.sigmoid(1.702 * h)                                       # QuickGELU
+            x = x + self._lin(h, pre + "fc2")
+        x = self._ln(x, "enc.ln_post", cfg.enc_ln_eps)
+        x = x.view(B, F, N, Dv)
+        if cfg.num_frames:
+            x = x + self.w["temporal"][:F][None, :, None, :]
+        return x.reshape(B, F * N, Dv)
+
+    # ------------------------------------------------------------------ projection (a4)
+    def project(self, visual: torch.Tensor) -> torch.Tensor:
+        return self._ln(self._lin(visual, "vproj"), "vproj.ln", self.cfg.proj_ln_eps)
+
+    # ------------------------------------------------------------------ text embedding (a5)
+    def embed_text(self, ids: torch.Tensor, pos0: int = 0) -> torch.Tensor:
+        T = ids.shape[1]
+        e = self.w["txt.word"][ids] + self.w["txt.pos"][pos0:pos0 + T][None]
+        return self._ln(e, "txt.ln", self.cfg.dec_ln_eps)
+
+    # ------------------------------------------------------------------ decoder (a6,a7)
+    def _dec_layer(self, i, x, k_all, v_all, klimit):
+        """x [B,Tq,D] query rows; k_all/v_all [B,H,Tk,64] all visible keys (incl. this block)."""
+        cfg = self.cfg
+        pre = f"dec.L{i}."
+        D, H = cfg.dec_width, cfg.dec_heads
+        qkv = _r(self._lin(x, pre + "qkv"), self.bf)
+        q = self._heads(qkv[..., :D], H)
+        a = self._merge(self._attn(q, k_all, v_all, klimit))
+        h = self._ln(self._lin(a, pre + "ao") + x, pre + "ln1", cfg.dec_ln_eps)
+        f = Fn.gelu(self._lin(h, pre + "fc1"))                                     # erf GELU
+        return self._ln(self._lin(f, pre + "fc2") + h, pre + "ln2", cfg.dec_ln_eps)
+
+    def _kv(self, i, x):
+        cfg = self.cfg
+        D, H = cfg.dec_width, cfg.dec_heads
+        qkv = _r(self._lin(x, f"dec.L{i}.qkv"), self.bf)
+        return self._heads(qkv[..., D:2 * D], H), self._heads(qkv[..., 2 * D:], H)
+
+    def decoder_full(self, memory: torch.Tensor, ids: torch.Tensor,
+                     return_hidden: bool = False):
+        """Full (no-cache) pass over [image ; text] with the GIT block mask:
+        image->image full, image->text blocked, text->image full, text->text causal
+        (model.py:412-418; mask per modeling_git.py:855-869).  memory = projected visual
+        features [B,S_img,D]; ids [B,T].  Returns logits [B,T,V]."""
+        cfg = self.cfg
+        S_img, T = memory.shape[1], ids.shape[1]
+        x = torch.cat([memory, self.embed_text(ids)], dim=1)
+        rows = torch.arange(S_img + T)
+        klimit = torch.where(rows < S_img, torch.full_like(rows, S_img), rows + 1)
+        hidden = []
+        for i in range(cfg.dec_layers):
+            k, v = self._kv(i, x)
+            x = self._dec_layer(i, x, k, v, klimit)
+            hidden.append(x)
+        logits = self._lin(x[:, S_img:], "head")
+        return (logits, hidden) if return_hidden else logits
+
+    # exact KV-cached variant (image K/V are text independent, so the cache is exact)
+    def prefill(self, memory: torch.Tensor, ids: torch.Tensor):
+        cfg = self.cfg
+        S_img, T = memory.shape[1], ids.shape[1]
+        x = torch.cat([memory, self.embed_text(ids)], dim=1)
+        rows = torch.arange(S_img + T)
+        klimit = torch.where(rows < S_img, torch.full_like(rows, S_img), rows + 1)
+        cache = []
+        for i in range(cfg.dec_layers):
+            k, v = self._kv(i, x)
+            cache.append([k, v])
+            x = self._dec_layer(i, x, k, v, klimit)
+        return self._lin(x[:, -1], "head"), cache, T
+
+    def step(self, cache, tok: torch.Tensor, t: int):
+        """tok [B] = token at text position t; returns logits [B,V] for position t+1."""
+        cfg = self.cfg
+        x = self.embed_text(tok[:, None], pos0=t)
+        for i in range(cfg.dec_layers):
+            k, v = self._kv(i, x)
+            cache[i][0] = torch.cat([cache[i][0], k], dim=2)
+            cache[i][1] = torch.cat([cache[i][1], v], dim=2)
+            Tk = cache[i][0].shape[2]
+            x = self._dec_layer(i, x, cache[i][0], cache[i][1], torch.tensor([Tk]))
+        return self._lin(x[:, -1], "head")
+
+    # ------------------------------------------------------------------ API restatements
+    def forward_image_enc(self, frames):
+        visual = self.encode_frames(frames)
+        return visual, self.project(visual)
+
+    def forward_output_logits(self, frames, ids):
+        """Teacher-forced logits [B,T,V] + visual features (model.py:747-760, batched)."""
+        visual, mem = self.forward_image_enc(frames)
+        return self.decoder_full(mem, ids), visual
+
+    def greedy_decode(self, frames: torch.Tensor, max_len: int = 20, stop: str = "all_sep",
+                      use_cache: bool = True, return_logits: bool = False):
+        """Restates StudentCandidateV1.greedy_decode (model.py:156-187) on the GIT arithmetic:
+        CLS start [B,1] (:171); <= max_len steps (:173); argmax of the last position (:178-180);
+        append (:182); stop iff ALL rows emitted SEP in the same step (:184).  stop='never'
+        disables the check (fixed-work benchmarking).  Returns int64 [B, 1+steps]."""
+        cfg = self.cfg
+        B = frames.shape[0]
+        _, mem = self.forward_image_enc(frames)
+        ids = torch.full((B, 1), cfg.cls_token_id, dtype=torch.long)
+        all_logits: List[torch.Tensor] = []
+        cache = None
+        for t in range(max_len):
+            if use_cache:
+                if cache is None:
+                    logits, cache, _ = self.prefill(mem, ids)
+                else:
+                    logits = self.step(cache, ids[:, -1], t)
+            else:
+                logits = self.decoder_full(mem, ids)[:, -1]
+            all_logits.append(logits)
+            nxt = logits.argmax(dim=-1, keepdim=True)
+            ids = torch.cat([ids, nxt], dim=1)
+            if stop == "all_sep" and bool(torch.all(nxt.squeeze(-1) == cfg.sep_token_id)):
+                break
+        return (ids, torch.stack(all_logits, 1)) if return_logits else ids
+
+
+def make_frames(B: int, F: int, size: int, seed: int = 1234) -> torch.Tensor:
+    """Synthetic CLIP-normalised-looking frames: numpy PCG64 so the same
+    tensor is regenerated bit-for-bit on any machine."""
+    g = np.random.default_rng(seed)
+    return torch.from_numpy(g.standard_normal((B, F, 3, size, size), dtype=np.float32))

@@ -1,0 +1,340 @@
+// Attention kernels for gfx950 (head_dim = 64 everywhere in GIT: ViT-B/16, ViT-L/14, decoder).
+//
+// attn_full_kernel: unmasked self-attention over groups of S rows (ViT frames, S = N; decoder
+//   image prefix, S = F*N).  Flash-style, one workgroup = 128 queries of one (group, head), 4 waves x
+//   32 queries.  Per 64-key tile:
+//     S^T = K . Q^T   (v_mfma_f32_32x32x16_bf16, K rows as A operand, Q as B operand) so that a lane
+//                     owns ONE query column: softmax max/sum are in-lane + one cross-half shuffle,
+//                     and the running rescale of O is a per-lane scalar.
+//     O^T += V^T . P^T  P^T is taken straight from the S^T accumulator registers (an accumulator
+//                     tile is a valid B operand for a product that sums over its row index,
+//                     cdna_hip_programming.md par. 3); V^T fragments come from ds_read_b64_tr_b16.
+//   K tile image: [64 keys][128 B], 16-B chunks XOR-swizzled (swz_chunk) -> conflict-free b128 reads.
+//   V tile image: [2 d-halves][64 keys][64 B] -> the 4 rows x 64 B of one transposed read cover the
+//                 256-B bank row exactly once.
+//   Both are filled by LDS-DMA (global_load_lds_dwordx4), double buffered, one barrier per tile.
+//
+// attn_text_kernel: text rows (prefill with T tokens or one decode step).  HBM-bound K/V
+//   streaming straight to VGPRs, 8 lanes per key row (16 B each), per-8-lane-group online softmax
+//   state so the inner loop has no cross-group traffic; groups/waves/splits are merged at the end.
+#include "kernels.h"
+
+namespace {
+
+constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict__ qkv,
+                                                        bf16_t* __restrict__ ctx, int S, int H) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 16384];   // per stage: K 8 KiB | V 8 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = blockIdx.y, grp = blockIdx.z;
+    const int W = H * 64, ld = 3 * W;
+    const size_t row0 = (size_t)grp * S;
+    const bf16_t* qbase = qkv + row0 * ld + head * 64;
+    const bf16_t* kbase = qbase + W;
+    const bf16_t* vbase = qbase + 2 * W;
+
+    const int l31 = lane & 31, h2 = lane >> 5;
+    const int q0 = blockIdx.x * 128 + wid * 32;
+    const int q = q0 + l31;
+    const bool wave_active = q0 < S;                 // wave-uniform
+
+    // Q fragments (B operand: B[k = d][col = q]); rows clamped, junk queries are never stored
+    bf16x8 qf[4];
+    {
+        const bf16_t* qp = qbase + (size_t)min(q, S - 1) * ld + h2 * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+    }
+
+    // ---- staging: wave w moves K pieces 2w,2w+1 (8 keys each) and V pieces 2w,2w+1 (16 keys of one d-half)
+    int k_key[2], k_src[2], v_key[2], v_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = wid * 2 + i;
+        k_key[i] = p * 8 + (lane >> 3);
+        k_src[i] = swz_chunk(k_key[i], lane & 7) * 8;
+        v_key[i] = (p & 3) * 16 + (lane >> 2);
+        v_src[i] = (p >> 2) * 32 + (lane & 3) * 8;
+    }
+    auto stage = [&](int buf, int key0) {
+        char* base = lds + buf * 16384 + wid * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kr = min(key0 + k_key[i], S - 1);
+            const int vr = min(key0 + v_key[i], S - 1);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(kbase + (size_t)kr * ld + k_src[i]), LDS_PTR(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(vbase + (size_t)vr * ld + v_src[i]), LDS_PTR(base + 8192 + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- per-lane read offsets
+    // K operand rows: key (32*kt + l31), chunk (2*ks + h2) swizzled by g(row); 32-aligned bases keep g = (l31>>1)&7
+    const int kg = (l31 >> 1) & 7;
+    const int k_off = l31 * 128;
+    // V transposed reads: 16-lane group (dgrp = (lane>>4)&1, h2); lane i=lane&15 supplies row i>>2, cols 4*(i&3)
+    const int v_off = 8192 + (4 * h2 + ((lane & 15) >> 2)) * 64 + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
+
+    f32x16 o_acc[2];
+    o_acc[0] = f32x16{0.f}; o_acc[1] = f32x16{0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o_acc[0][r] = 0.f; o_acc[1][r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (S + 63) >> 6;
+    stage(0, 0);
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < ntiles) stage((t + 1) & 1, (t + 1) * 64);
+        if (!wave_active) continue;
+        const char* sb = lds + (t & 1) * 16384;
+        const int key0 = t * 64;
+
+        // ---- S^T = K . Q^T -----------------------------------------------------------------
+        f32x16 s_acc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_acc[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(sb + kt * 4096 + k_off + (((2 * ks + h2) ^ kg) << 4));
+                s_acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[kt], 0, 0, 0);
+            }
+        }
+        // ---- mask the ragged last tile (wave-uniform branch) ---------------------------------
+        if (key0 + 64 > S) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                    if (key >= S) s_acc[kt][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax (lane = query; its 32 keys + the other half-wave's 32) ------------
+        float mt = s_acc[0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s_acc[kt][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = fast_exp2((m_run - m_new) * kScaleLog2e);
+        const float mb = m_new * kScaleLog2e;
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = fast_exp2(s_acc[kt][r] * kScaleLog2e - mb);
+                s_acc[kt][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o_acc[0][r] *= alpha; o_acc[1][r] *= alpha; }
+
+        // ---- O^T += V^T . P^T -----------------------------------------------------------------
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(s_acc[kt][8 * s + j]);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const char* vp = sb + v_off + dt * 4096 + (32 * kt + 16 * s) * 64;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(vp));
+                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(vp + 8 * 64));
+                    const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[dt], 0, 0, 0);
+                }
+            }
+    }
+
+    if (wave_active) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        const float inv = 1.0f / l_tot;
+        if (q < S) {
+            bf16_t* op = ctx + (row0 + q) * (size_t)W + head * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int d = dt * 32 + 8 * rq + 4 * h2;
+                    uint2 v;
+                    v.x = pack_bf2(o_acc[dt][4 * rq + 0] * inv, o_acc[dt][4 * rq + 1] * inv);
+                    v.y = pack_bf2(o_acc[dt][4 * rq + 2] * inv, o_acc[dt][4 * rq + 3] * inv);
+                    *(uint2*)(op + d) = v;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// text rows
+// ------------------------------------------------------------------------------------------
+struct Part { float m, l; float o[8]; };
+
+__device__ __forceinline__ void merge(Part& a, float m2, float l2, const float* o2) {
+    const float M = fmaxf(a.m, m2);
+    const float s1 = (a.m == -INFINITY) ? 0.f : fast_exp2(a.m - M);
+    const float s2 = (m2 == -INFINITY) ? 0.f : fast_exp2(m2 - M);
+    a.l = a.l * s1 + l2 * s2;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) a.o[d] = a.o[d] * s1 + o2[d] * s2;
+    a.m = M;
+}
+
+__global__ __launch_bounds__(256) void attn_text_kernel(TextAttnArgs a) {
+    __shared__ float wsm[4][8][10];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = blockIdx.x, head = blockIdx.y, split = blockIdx.z;
+    const int r = m / a.T, j = m - r * a.T;
+    const int clip = r / a.beams;
+    const int D = a.D, ld = 3 * D;
+    const int tq = a.t0 + j;
+    const int Lk = a.S_img + tq + 1;
+    const int chunk = (Lk + a.nsplit - 1) / a.nsplit;
+    const int kbeg = split * chunk;
+    const int kend = min(Lk, kbeg + chunk);
+    const int sub = lane & 7, kk = lane >> 3;
+
+    const bf16_t* img = a.kv_img + (size_t)clip * a.S_img * ld + D + head * 64 + sub * 8;
+    const bf16_t* txt = a.kv_txt + (size_t)r * a.Tmax * ld + D + head * 64 + sub * 8;
+
+    float qv[8];
+    {
+        const bf16x8 q8 = *(const bf16x8*)(a.kv_txt + ((size_t)r * a.Tmax + tq) * ld + head * 64 + sub * 8);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) qv[d] = bf2f((bf16_t)q8[d]) * kScaleLog2e;
+    }
+    Part st;
+    st.m = -INFINITY; st.l = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) st.o[d] = 0.f;
+
+    for (int g0 = kbeg + wid * 32; g0 < kend; g0 += 128) {
+        bf16x8 kf[4], vf[4];
+        bool valid[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int key = g0 + u * 8 + kk;
+            valid[u] = key < kend;
+            key = valid[u] ? key : kbeg;                        // kbeg < kend is guaranteed inside the loop
+            const bf16_t* kp = key < a.S_img ? img + (size_t)key * ld : txt + (size_t)(key - a.S_img) * ld;
+            kf[u] = *(const bf16x8*)kp;
+            vf[u] = *(const bf16x8*)(kp + D);
+        }
+        float sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) s += qv[d] * bf2f((bf16_t)kf[u][d]);
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            sc[u] = valid[u] ? s : -INFINITY;
+        }
+        const float mt = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        const float m_new = fmaxf(st.m, mt);
+        if (m_new != -INFINITY) {
+            const float alpha = (st.m == -INFINITY) ? 0.f : fast_exp2(st.m - m_new);
+            st.l *= alpha;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) st.o[d] *= alpha;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float p = fast_exp2(sc[u] - m_new);       // exp2(-inf) = 0 for masked keys
+                st.l += p;
+                const float pb = bf2f(f2bf(p));                 // P enters the PV product as bf16 (same rule as the MFMA path)
+#pragma unroll
+                for (int d = 0; d < 8; ++d) st.o[d] += pb * bf2f((bf16_t)vf[u][d]);
+            }
+            st.m = m_new;
+        }
+    }
+    // merge the 8 key-groups of the wave (lanes with equal sub)
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+        const float m2 = __shfl_xor(st.m, off), l2 = __shfl_xor(st.l, off);
+        float o2[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) o2[d] = __shfl_xor(st.o[d], off);
+        merge(st, m2, l2, o2);
+    }
+    if (kk == 0) {
+        wsm[wid][sub][0] = st.m; wsm[wid][sub][1] = st.l;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) wsm[wid][sub][2 + d] = st.o[d];
+    }
+    __syncthreads();
+    if (tid < 8) {
+        Part t;
+        t.m = wsm[0][tid][0]; t.l = wsm[0][tid][1];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) t.o[d] = wsm[0][tid][2 + d];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) merge(t, wsm[w][tid][0], wsm[w][tid][1], &wsm[w][tid][2]);
+        if (a.nsplit == 1) {
+            const float inv = 1.0f / t.l;
+            uint4 v;
+            v.x = pack_bf2(t.o[0] * inv, t.o[1] * inv); v.y = pack_bf2(t.o[2] * inv, t.o[3] * inv);
+            v.z = pack_bf2(t.o[4] * inv, t.o[5] * inv); v.w = pack_bf2(t.o[6] * inv, t.o[7] * inv);
+            *(uint4*)(a.ctx + (size_t)m * D + head * 64 + tid * 8) = v;
+        } else {
+            float* pp = a.part + (((size_t)m * a.H + head) * a.nsplit + split) * 66;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) pp[tid * 8 + d] = t.o[d];
+            if (tid == 0) { pp[64] = t.m; pp[65] = t.l; }
+        }
+    }
+}
+
+// merge split partials: one wave per (m, head); lane = d
+__global__ __launch_bounds__(64) void attn_text_combine(const float* __restrict__ part, bf16_t* __restrict__ ctx,
+                                                        int H, int D, int nsplit) {
+    const int m = blockIdx.x, head = blockIdx.y, d = threadIdx.x;
+    const float* pp = part + ((size_t)m * H + head) * nsplit * 66;
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pp[s * 66 + 64]);
+    float l = 0.f, o = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float ms = pp[s * 66 + 64];
+        const float sc = (ms == -INFINITY) ? 0.f : fast_exp2(ms - M);
+        l += pp[s * 66 + 65] * sc;
+        o += pp[s * 66 + d] * sc;
+    }
+    ctx[(size_t)m * D + head * 64 + d] = f2bf(o / l);
+}
+
+}  // namespace
+
+hipError_t launch_attn_full(const bf16_t* qkv, bf16_t* ctx, int G, int S, int H, hipStream_t s) {
+    if (G <= 0 || S <= 0 || H <= 0) return hipErrorInvalidValue;
+    dim3 grid((S + 127) / 128, H, G);
+    hipLaunchKernelGGL(attn_full_kernel, grid, dim3(256), 0, s, qkv, ctx, S, H);
+    return hipGetLastError();
+}
+
+hipError_t launch_attn_text(const TextAttnArgs& a, hipStream_t s) {
+    const int M = a.rows * a.T;
+    if (M <= 0 || a.nsplit < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_text_kernel, dim3(M, a.H, a.nsplit), dim3(256), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (a.nsplit > 1) {
+        hipLaunchKernelGGL(attn_text_combine, dim3(M, a.H), dim3(64), 0, s, a.part, a.ctx, a.H, a.D, a.nsplit);
+        e = hipGetLastError();
+    }
+    return e;
+}

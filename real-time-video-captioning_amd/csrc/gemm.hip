@@ -1,0 +1,163 @@
+// bf16 MFMA GEMM for gfx950:  C[m][n] = sum_k A[m][k] * W[n][k]  with fused epilogues.
+//
+// Both operands are K-contiguous ("B^T" form), which is exactly what the MFMA A/B lane maps
+// want: lane l of v_mfma_f32_16x16x32_bf16 holds 8 consecutive k of row (l & 15).
+//
+// Tile 128(m) x 128(n) x 64(k), 256 threads = 4 waves as 2(m) x 2(n), each wave 64x64 =
+// 4x4 MFMA tiles.  The WEIGHT rows are the MFMA "A" operand and the ACTIVATION rows the "B"
+// operand, so an accumulator register quad holds 4 consecutive n of one m: the epilogue reads
+// bias / residual and writes the output as 8- or 16-byte vectors along the contiguous dimension.
+//
+// Staging: global_load_lds_dwordx4 (LDS-DMA, 1 KiB per wave-instruction) into a double-buffered
+// 2 x (16 KiB A + 16 KiB W) image.  The LDS image is lane-linear, so the bank-conflict swizzle is
+// applied to the per-lane SOURCE address and again on the ds_read_b128 (rule 21 of the CDNA guide).
+// One barrier per k-tile: tile t+1 is in flight while tile t is multiplied.
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * BK * 2;           // 16 KiB per operand per stage
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;        // A then W
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;         // 64 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntn = a.N / BN;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lid / ntn, tn = lid - tm * ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    // ---- staging addresses: wave w moves pieces p = 4w .. 4w+3 (8 rows x 128 B each) ----------
+    const int srow = lane >> 3;                     // row inside a piece
+    const int schunk = lane & 7;                    // LDS chunk position inside the row
+    const bf16_t* gA[4];
+    const bf16_t* gW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wid * 4 + i) * 8 + srow;   // 0..127
+        const int src_chunk = swz_chunk(row, schunk);
+        gA[i] = a.A + (size_t)(m0 + row) * a.lda + src_chunk * 8;
+        gW[i] = a.W + (size_t)(n0 + row) * a.K + src_chunk * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+        char* base = smem + buf * STAGE_BYTES + wid * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(gA[i] + k0), LDS_PTR(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(gW[i] + k0), LDS_PTR(base + TILE_BYTES + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets ---------------------------------------------------------------
+    const int frow = lane & 15, fq = lane >> 4;     // operand row within a 16-tile, k-quarter
+    int offW[4], offA[4];                           // byte offsets of the row starts in a stage
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        offW[i] = TILE_BYTES + (wn * 64 + i * 16 + frow) * 128;
+        offA[i] = (wm * 64 + i * 16 + frow) * 128;
+    }
+    const int g = (frow >> 1) & 7;                  // swizzle key of this lane's rows (16-aligned bases)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nt = a.K / BK;
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage((t + 1) & 1, (t + 1) * BK);
+        const char* sb = smem + (t & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + fq) ^ g) * 16;
+            bf16x8 wf[4], af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = *(const bf16x8*)(sb + offW[i] + coff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af[j] = *(const bf16x8*)(sb + offA[j] + coff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane holds n = nb + 4*fq + {0..3}, m = mb + frow for each (i, j) ------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + fq * 4;
+        f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EPI != EPI_PATCH_F32 && a.bias) bias4 = *(const f32x4*)(a.bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + frow;
+            f32x4 v = acc[i][j] + bias4;
+            if (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16) {
+                if (EPI == EPI_BIAS_QGELU_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
+                } else if (EPI == EPI_BIAS_GELU_BF16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = erf_gelu(v[r]);
+                }
+                uint2 o;
+                o.x = pack_bf2(v[0], v[1]);
+                o.y = pack_bf2(v[2], v[3]);
+                *(uint2*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = o;
+            } else if (EPI == EPI_BIAS_RESID_F32) {
+                const f32x4 r4 = *(const f32x4*)(a.resid + (size_t)m * a.ldr + n);
+                *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v + r4;
+            } else if (EPI == EPI_BIAS_F32) {
+                *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;
+            } else {  // EPI_PATCH_F32: m = frame*P + patch  ->  row frame*N + 1 + patch, + pos[1+patch]
+                if (m < a.valid_rows) {
+                    const int frame = m / a.patches_per_frame;
+                    const int patch = m - frame * a.patches_per_frame;
+                    const f32x4 p4 = *(const f32x4*)(a.pos + (size_t)(1 + patch) * a.N + n);
+                    const size_t orow = (size_t)frame * a.tokens_per_frame + 1 + patch;
+                    *(f32x4*)((float*)a.out + orow * a.ldo + n) = acc[i][j] + p4;
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = (a.M / BM) * (a.N / BN);
+    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(grid), dim3(256), LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s) {
+    if (a.M % BM || a.N % BN || a.K % BK || a.M <= 0) return hipErrorInvalidValue;
+    switch (epi) {
+        case EPI_BIAS_BF16: return launch_t<EPI_BIAS_BF16>(a, s);
+        case EPI_BIAS_QGELU_BF16: return launch_t<EPI_BIAS_QGELU_BF16>(a, s);
+        case EPI_BIAS_GELU_BF16: return launch_t<EPI_BIAS_GELU_BF16>(a, s);
+        case EPI_BIAS_RESID_F32: return launch_t<EPI_BIAS_RESID_F32>(a, s);
+        case EPI_BIAS_F32: return launch_t<EPI_BIAS_F32>(a, s);
+        case EPI_PATCH_F32: return launch_t<EPI_PATCH_F32>(a, s);
+    }
+    return hipErrorInvalidValue;
+}

@@ -1,0 +1,505 @@
+// libgitcap C ABI: handle, weights, workspace and the launch sequences of the GIT caption path.
+// Declarations and the reference call each entry point replaces: include/gitcap.h.
+#include "../../include/gitcap.h"
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#define GITCAP_ABI_VERSION 1
+
+namespace {
+
+struct DevTensor {
+    void* p = nullptr;
+    std::vector<int64_t> shape;   // logical (unpadded) shape
+    bool bf16 = false;
+    bool loaded = false;
+};
+
+inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+uint16_t host_f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+struct EncLayer {
+    const float *ln1w, *ln1b, *ln2w, *ln2b, *qkvb, *projb, *fc1b, *fc2b;
+    const bf16_t *qkvw, *projw, *fc1w, *fc2w;
+};
+struct DecLayer {
+    const float *qkvb, *aob, *ln1w, *ln1b, *fc1b, *fc2b, *ln2w, *ln2b;
+    const bf16_t *qkvw, *aow, *fc1w, *fc2w;
+};
+
+}  // namespace
+
+struct gitcap {
+    gitcap_config c;
+    int device = 0;
+    mutable std::string err;
+    std::map<std::string, DevTensor> w;
+    bool finalized = false;
+
+    // derived sizes
+    int N = 0, G = 0, Kp = 0, Dv = 0, D = 0, V = 0, Vp = 0;
+    int Smax = 0, Mi = 0, Pp = 0, R = 0, Tmax = 0, Mt = 0;
+    int64_t ws_bytes = 0;
+    std::vector<void*> allocs;
+
+    // workspace (image rows)
+    float *x = nullptr, *tmp = nullptr, *visual = nullptr;
+    bf16_t *hb = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr, *patches = nullptr, *kv_img = nullptr;
+    // workspace (text rows)
+    float *xs = nullptr, *ts = nullptr, *logits = nullptr, *part = nullptr;
+    bf16_t *xsb = nullptr, *cs = nullptr, *fs = nullptr, *kv_txt = nullptr, *kv_txt2 = nullptr;
+    int32_t* sep_cnt = nullptr;
+
+    // resolved weights
+    const bf16_t *patch_w = nullptr, *vproj_w = nullptr, *head_w = nullptr;
+    const float *cls = nullptr, *pos = nullptr, *ln_pre_w = nullptr, *ln_pre_b = nullptr, *ln_post_w = nullptr,
+                *ln_post_b = nullptr, *temporal = nullptr, *vproj_b = nullptr, *vproj_lnw = nullptr,
+                *vproj_lnb = nullptr, *word = nullptr, *tpos = nullptr, *txt_lnw = nullptr, *txt_lnb = nullptr,
+                *head_b = nullptr;
+    std::vector<EncLayer> enc;
+    std::vector<DecLayer> dec;
+
+    // state
+    int cur_B = 0, cur_S = 0;
+    bool have_image = false;
+};
+
+namespace {
+
+std::string g_create_err;
+
+int fail(const gitcap* h, int code, const std::string& msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HIP_OK(h, expr)                                                                               \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(h, GITCAP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+// canonical names -> (shape, is_gemm_weight); mirrors gitcap/weights.py:canonical_shapes
+void expected_shapes(const gitcap_config& c, std::vector<std::pair<std::string, std::vector<int64_t>>>& out) {
+    const int64_t Dv = c.enc_width, D = c.dec_width, V = c.vocab_size;
+    const int64_t G = c.image_size / c.patch_size, N = G * G + 1, pd = 3LL * c.patch_size * c.patch_size;
+    auto add = [&](const std::string& n, std::vector<int64_t> s) { out.emplace_back(n, std::move(s)); };
+    add("enc.patch_w", {Dv, pd}); add("enc.cls", {Dv}); add("enc.pos", {N, Dv});
+    add("enc.ln_pre.w", {Dv}); add("enc.ln_pre.b", {Dv}); add("enc.ln_post.w", {Dv}); add("enc.ln_post.b", {Dv});
+    for (int i = 0; i < c.enc_layers; ++i) {
+        const std::string p = "enc.L" + std::to_string(i) + ".";
+        add(p + "ln1.w", {Dv}); add(p + "ln1.b", {Dv});
+        add(p + "qkv.w", {3 * Dv, Dv}); add(p + "qkv.b", {3 * Dv});
+        add(p + "proj.w", {Dv, Dv}); add(p + "proj.b", {Dv});
+        add(p + "ln2.w", {Dv}); add(p + "ln2.b", {Dv});
+        add(p + "fc1.w", {c.enc_ffn, Dv}); add(p + "fc1.b", {c.enc_ffn});
+        add(p + "fc2.w", {Dv, c.enc_ffn}); add(p + "fc2.b", {Dv});
+    }
+    add("temporal", {std::max(1, c.num_frames), Dv});
+    add("vproj.w", {D, Dv}); add("vproj.b", {D}); add("vproj.ln.w", {D}); add("vproj.ln.b", {D});
+    add("txt.word", {V, D}); add("txt.pos", {c.max_text_pos, D}); add("txt.ln.w", {D}); add("txt.ln.b", {D});
+    for (int i = 0; i < c.dec_layers; ++i) {
+        const std::string p = "dec.L" + std::to_string(i) + ".";
+        add(p + "qkv.w", {3 * D, D}); add(p + "qkv.b", {3 * D});
+        add(p + "ao.w", {D, D}); add(p + "ao.b", {D});
+        add(p + "ln1.w", {D}); add(p + "ln1.b", {D});
+        add(p + "fc1.w", {c.dec_ffn, D}); add(p + "fc1.b", {c.dec_ffn});
+        add(p + "fc2.w", {D, c.dec_ffn}); add(p + "fc2.b", {D});
+        add(p + "ln2.w", {D}); add(p + "ln2.b", {D});
+    }
+    add("head.w", {V, D}); add("head.b", {V});
+}
+
+bool is_gemm_weight(const std::string& n) {
+    if (n == "enc.patch_w" || n == "vproj.w" || n == "head.w") return true;
+    auto ends = [&](const char* s) { size_t l = strlen(s); return n.size() >= l && n.compare(n.size() - l, l, s) == 0; };
+    return ends("qkv.w") || ends("proj.w") || ends("fc1.w") || ends("fc2.w") || ends("ao.w");
+}
+
+template <typename T>
+int ws_alloc(gitcap* h, T** p, size_t count) {
+    void* q = nullptr;
+    const size_t bytes = count * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(h, GITCAP_ERR_NOMEM, std::string("hipMalloc workspace: ") + hipGetErrorString(e));
+    e = hipMemset(q, 0, bytes);
+    if (e != hipSuccess) return fail(h, GITCAP_ERR_HIP, std::string("hipMemset workspace: ") + hipGetErrorString(e));
+    h->allocs.push_back(q);
+    h->ws_bytes += (int64_t)bytes;
+    *p = (T*)q;
+    return 0;
+}
+
+int ln(gitcap* h, hipStream_t s, const float* x, int ldx, const float* g, const float* b, float eps, int rows, int D,
+       float* of, int ldf, bf16_t* ob, int ldb, const float* addv = nullptr, int add_div = 1, int add_mod = 1) {
+    LnArgs a{x, ldx, g, b, eps, rows, D, of, ldf, ob, ldb, addv, add_div, add_mod};
+    HIP_OK(h, launch_layernorm(a, s));
+    return 0;
+}
+
+int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const bf16_t* W, const float* bias, int M, int N,
+         int K, void* out, int ldo, const float* resid = nullptr, int ldr = 0) {
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
+    a.resid = resid; a.ldr = ldr;
+    HIP_OK(h, launch_gemm(a, epi, s));
+    return 0;
+}
+
+int skinny(gitcap* h, hipStream_t s, int epi, const bf16_t* X, int ldx, const bf16_t* W, const float* bias, int M,
+           int N, int K, void* out, int ldo, int T = 1, int row_stride = 1, int row_off = 0,
+           const float* resid = nullptr, int ldr = 0) {
+    SkinnyArgs a{X, ldx, W, bias, M, N, K, out, ldo, T, row_stride, row_off, resid, ldr};
+    HIP_OK(h, launch_skinny(a, epi, s));
+    return 0;
+}
+
+// projected image tokens -> decoder layers over image rows only; fills kv_img (text independent)
+int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
+    const gitcap_config& c = h->c;
+    const int D = h->D, Dv = h->Dv, rows = B * S, Mp = pad_to(rows, 128);
+    int rc;
+    // 'linearLn' projection: Linear(Dv -> D) + LayerNorm
+    if ((rc = gemm(h, s, EPI_BIAS_F32, h->hb, Dv, h->vproj_w, h->vproj_b, Mp, D, Dv, h->tmp, D))) return rc;
+    if ((rc = ln(h, s, h->tmp, D, h->vproj_lnw, h->vproj_lnb, c.proj_ln_eps, rows, D, h->x, D, h->hb, D))) return rc;
+    const size_t kv_layer = (size_t)h->Mi * 3 * D;
+    for (int l = 0; l < c.dec_layers; ++l) {
+        const DecLayer& L = h->dec[l];
+        bf16_t* kv = h->kv_img + (size_t)l * kv_layer;
+        if (l + 1 < c.dec_layers) {
+            if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, D, L.qkvw, L.qkvb, Mp, 3 * D, D, kv, 3 * D))) return rc;
+            HIP_OK(h, launch_attn_full(kv, h->ctx, B, S, c.dec_heads, s));
+            if ((rc = gemm(h, s, EPI_BIAS_RESID_F32, h->ctx, D, L.aow, L.aob, Mp, D, D, h->tmp, D, h->x, D))) return rc;
+            if ((rc = ln(h, s, h->tmp, D, L.ln1w, L.ln1b, c.dec_ln_eps, rows, D, h->x, D, h->hb, D))) return rc;
+            if ((rc = gemm(h, s, EPI_BIAS_GELU_BF16, h->hb, D, L.fc1w, L.fc1b, Mp, c.dec_ffn, D, h->ffn, c.dec_ffn))) return rc;
+            if ((rc = gemm(h, s, EPI_BIAS_RESID_F32, h->ffn, c.dec_ffn, L.fc2w, L.fc2b, Mp, D, c.dec_ffn, h->tmp, D, h->x, D))) return rc;
+            if ((rc = ln(h, s, h->tmp, D, L.ln2w, L.ln2b, c.dec_ln_eps, rows, D, h->x, D, h->hb, D))) return rc;
+        } else {
+            // last layer: image rows are only ever read as keys/values -> K,V projections only
+            if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, D, L.qkvw + (size_t)D * D, L.qkvb + D, Mp, 2 * D, D, kv + D, 3 * D))) return rc;
+        }
+    }
+    h->cur_B = B; h->cur_S = S; h->have_image = true;
+    return 0;
+}
+
+int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams, int t0, int T, float* logits_out,
+                 int all_positions, int64_t* argmax_out, int ld_argmax, int32_t* sep_cnt, int step, hipStream_t s) {
+    const gitcap_config& c = h->c;
+    if (!h->finalized) return fail(h, GITCAP_ERR_STATE, "weights not finalized");
+    if (!h->have_image) return fail(h, GITCAP_ERR_STATE, "text_forward before encode/set_visual");
+    if (!ids || rows <= 0 || beams <= 0 || T <= 0 || t0 < 0) return fail(h, GITCAP_ERR_ARG, "text_forward: bad arguments");
+    if (rows != h->cur_B * beams) return fail(h, GITCAP_ERR_ARG, "text_forward: rows != encoded clips * beams");
+    if (rows > h->R) return fail(h, GITCAP_ERR_ARG, "text_forward: rows exceed max_batch*max_beams");
+    if (t0 + T > h->Tmax) return fail(h, GITCAP_ERR_ARG, "text_forward: t0+T exceeds max_text_len");
+    if (t0 + T > c.max_text_pos) return fail(h, GITCAP_ERR_ARG, "text_forward: position exceeds max_text_pos");
+    const int D = h->D, M = rows * T, H = c.dec_heads;
+    int rc;
+    HIP_OK(h, launch_embed_text(ids, ld_ids, rows, T, t0, h->word, h->tpos, h->txt_lnw, h->txt_lnb, c.dec_ln_eps, D,
+                                c.vocab_size, h->xs, h->xsb, s));
+    int nsplit = (768 + M * H - 1) / (M * H);
+    nsplit = nsplit < 1 ? 1 : (nsplit > 8 ? 8 : nsplit);
+    const size_t kvi_layer = (size_t)h->Mi * 3 * D, kvt_layer = (size_t)h->R * h->Tmax * 3 * D;
+    for (int l = 0; l < c.dec_layers; ++l) {
+        const DecLayer& L = h->dec[l];
+        bf16_t* kvt = h->kv_txt + (size_t)l * kvt_layer;
+        if ((rc = skinny(h, s, SK_BIAS_BF16, h->xsb, D, L.qkvw, L.qkvb, M, 3 * D, D, kvt, 3 * D, T, h->Tmax, t0))) return rc;
+        TextAttnArgs ta{h->kv_img + (size_t)l * kvi_layer, kvt, h->cs, h->part, rows, beams, t0, T, h->Tmax, h->cur_S, H, D, nsplit};
+        HIP_OK(h, launch_attn_text(ta, s));
+        if ((rc = skinny(h, s, SK_BIAS_RESID_F32, h->cs, D, L.aow, L.aob, M, D, D, h->ts, D, 1, 1, 0, h->xs, D))) return rc;
+        if ((rc = ln(h, s, h->ts, D, L.ln1w, L.ln1b, c.dec_ln_eps, M, D, h->xs, D, h->xsb, D))) return rc;
+        if ((rc = skinny(h, s, SK_BIAS_GELU_BF16, h->xsb, D, L.fc1w, L.fc1b, M, c.dec_ffn, D, h->fs, c.dec_ffn))) return rc;
+        if ((rc = skinny(h, s, SK_BIAS_RESID_F32, h->fs, c.dec_ffn, L.fc2w, L.fc2b, M, D, c.dec_ffn, h->ts, D, 1, 1, 0, h->xs, D))) return rc;
+        if ((rc = ln(h, s, h->ts, D, L.ln2w, L.ln2b, c.dec_ln_eps, M, D, h->xs, D, h->xsb, D))) return rc;
+    }
+    if (!logits_out && !argmax_out) return 0;
+    const int V = c.vocab_size;
+    const float* last_logits;
+    int last_ld;
+    if (all_positions && logits_out) {
+        if ((rc = skinny(h, s, SK_BIAS_F32, h->xsb, D, h->head_w, h->head_b, M, V, D, logits_out, V))) return rc;
+        last_logits = logits_out + (size_t)(T - 1) * V;
+        last_ld = T * V;
+    } else {
+        float* dst = logits_out ? logits_out : h->logits;
+        if ((rc = skinny(h, s, SK_BIAS_F32, h->xsb + (size_t)(T - 1) * D, T * D, h->head_w, h->head_b, rows, V, D, dst, V))) return rc;
+        last_logits = dst;
+        last_ld = V;
+    }
+    if (argmax_out)
+        HIP_OK(h, launch_argmax(last_logits, last_ld, rows, V, argmax_out, ld_argmax, sep_cnt, step, c.sep_token_id, s));
+    return 0;
+}
+
+int check_frames(gitcap* h, const float* frames, int B, int F) {
+    if (!h->finalized) return fail(h, GITCAP_ERR_STATE, "weights not finalized");
+    if (!frames || B <= 0 || F <= 0) return fail(h, GITCAP_ERR_ARG, "encode: bad arguments");
+    if (B > h->c.max_batch || F > h->c.max_frames) return fail(h, GITCAP_ERR_ARG, "encode: B/F exceed the sizes the handle was created for");
+    if (h->c.num_frames > 0 && F > h->c.num_frames) return fail(h, GITCAP_ERR_ARG, "encode: more frames than temporal embeddings");
+    if (((uintptr_t)frames & 15) != 0) return fail(h, GITCAP_ERR_ARG, "encode: frames must be 16-byte aligned");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gitcap_abi_version(void) { return GITCAP_ABI_VERSION; }
+
+const char* gitcap_last_error(const gitcap_t* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
+    if (!cfg || !out) return fail(nullptr, GITCAP_ERR_ARG, "create: null argument");
+    *out = nullptr;
+    const gitcap_config& c = *cfg;
+    if (c.patch_size <= 0 || c.image_size % c.patch_size) return fail(nullptr, GITCAP_ERR_ARG, "create: image_size % patch_size != 0");
+    if (c.enc_heads * 64 != c.enc_width || c.dec_heads * 64 != c.dec_width)
+        return fail(nullptr, GITCAP_ERR_ARG, "create: head_dim must be 64");
+    for (int n : {c.enc_width, c.enc_ffn, c.dec_width, c.dec_ffn})
+        if (n % 128) return fail(nullptr, GITCAP_ERR_ARG, "create: widths must be multiples of 128");
+    if (c.enc_width > 1024 || c.dec_width > 1024) return fail(nullptr, GITCAP_ERR_ARG, "create: width > 1024 unsupported");
+    if (c.max_batch <= 0 || c.max_frames <= 0 || c.max_text_len <= 0 || c.max_beams <= 0)
+        return fail(nullptr, GITCAP_ERR_ARG, "create: max_* must be positive");
+    if (c.patch_size % 2) return fail(nullptr, GITCAP_ERR_ARG, "create: odd patch_size unsupported");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, GITCAP_ERR_HIP, "create: no HIP device visible (libgitcap has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(nullptr, GITCAP_ERR_ARG, "create: bad device index");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, GITCAP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+
+    gitcap* h = new (std::nothrow) gitcap();
+    if (!h) return fail(nullptr, GITCAP_ERR_NOMEM, "create: out of host memory");
+    h->c = c; h->device = device;
+    h->G = c.image_size / c.patch_size; h->N = h->G * h->G + 1;
+    h->Kp = pad_to(3 * c.patch_size * c.patch_size, 64);
+    h->Dv = c.enc_width; h->D = c.dec_width; h->V = c.vocab_size; h->Vp = pad_to(c.vocab_size, 16);
+    h->Smax = c.max_frames * h->N;
+    h->Mi = pad_to(c.max_batch * h->Smax, 128);
+    h->Pp = pad_to(c.max_batch * c.max_frames * h->G * h->G, 128);
+    h->R = c.max_batch * c.max_beams; h->Tmax = c.max_text_len;
+    h->Mt = pad_to(h->R * h->Tmax, 16);
+    const int Dm = std::max(h->Dv, h->D), Fm = std::max(c.enc_ffn, c.dec_ffn);
+    int rc = 0;
+    const size_t Mi = h->Mi, Mt = h->Mt;
+    rc = rc ? rc : ws_alloc(h, &h->x, Mi * Dm);
+    rc = rc ? rc : ws_alloc(h, &h->tmp, Mi * h->D);
+    rc = rc ? rc : ws_alloc(h, &h->visual, Mi * h->Dv);
+    rc = rc ? rc : ws_alloc(h, &h->hb, Mi * Dm);
+    rc = rc ? rc : ws_alloc(h, &h->qkv, Mi * 3 * h->Dv);
+    rc = rc ? rc : ws_alloc(h, &h->ctx, Mi * Dm);
+    rc = rc ? rc : ws_alloc(h, &h->ffn, Mi * Fm);
+    rc = rc ? rc : ws_alloc(h, &h->patches, (size_t)h->Pp * h->Kp);
+    rc = rc ? rc : ws_alloc(h, &h->kv_img, (size_t)c.dec_layers * Mi * 3 * h->D);
+    rc = rc ? rc : ws_alloc(h, &h->xs, Mt * h->D);
+    rc = rc ? rc : ws_alloc(h, &h->ts, Mt * h->D);
+    rc = rc ? rc : ws_alloc(h, &h->xsb, Mt * h->D);
+    rc = rc ? rc : ws_alloc(h, &h->cs, Mt * h->D);
+    rc = rc ? rc : ws_alloc(h, &h->fs, Mt * c.dec_ffn);
+    rc = rc ? rc : ws_alloc(h, &h->logits, (size_t)h->R * h->V);
+    rc = rc ? rc : ws_alloc(h, &h->part, Mt * c.dec_heads * 8 * 66);
+    rc = rc ? rc : ws_alloc(h, &h->kv_txt, (size_t)c.dec_layers * h->R * h->Tmax * 3 * h->D);
+    rc = rc ? rc : ws_alloc(h, &h->kv_txt2, (size_t)c.dec_layers * h->R * h->Tmax * 3 * h->D);
+    rc = rc ? rc : ws_alloc(h, &h->sep_cnt, (size_t)h->Tmax + 1);
+    if (rc) {
+        g_create_err = h->err;
+        gitcap_destroy(h);
+        return rc;
+    }
+    std::vector<std::pair<std::string, std::vector<int64_t>>> exp;
+    expected_shapes(c, exp);
+    for (auto& kv : exp) {
+        DevTensor t;
+        t.shape = kv.second;
+        t.bf16 = is_gemm_weight(kv.first);
+        h->w[kv.first] = t;
+    }
+    *out = h;
+    return 0;
+}
+
+void gitcap_destroy(gitcap_t* h) {
+    if (!h) return;
+    for (void* p : h->allocs) (void)hipFree(p);
+    for (auto& kv : h->w)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    delete h;
+}
+
+int gitcap_load_tensor(gitcap_t* h, const char* name, const float* data, const int64_t* shape, int rank) {
+    if (!h || !name || !data || !shape) return fail(h, GITCAP_ERR_ARG, "load_tensor: null argument");
+    auto it = h->w.find(name);
+    if (it == h->w.end()) return fail(h, GITCAP_ERR_ARG, std::string("load_tensor: unknown tensor '") + name + "'");
+    DevTensor& t = it->second;
+    if ((int)t.shape.size() != rank) return fail(h, GITCAP_ERR_ARG, std::string("load_tensor: rank mismatch for ") + name);
+    for (int i = 0; i < rank; ++i)
+        if (t.shape[i] != shape[i]) return fail(h, GITCAP_ERR_ARG, std::string("load_tensor: shape mismatch for ") + name);
+    HIP_OK(h, hipSetDevice(h->device));
+    const int64_t rows = rank == 2 ? shape[0] : 1, cols = rank == 2 ? shape[1] : shape[0];
+    if (t.p) { (void)hipFree(t.p); t.p = nullptr; }
+    if (t.bf16) {
+        // GEMM weights: bf16, rows padded to 16 (zero rows), patch-embed K padded to a multiple of 64
+        const int64_t prow = pad_to((int)rows, 16), pcol = (strcmp(name, "enc.patch_w") == 0) ? h->Kp : cols;
+        std::vector<uint16_t> hb((size_t)prow * pcol, 0);
+        for (int64_t r = 0; r < rows; ++r)
+            for (int64_t k = 0; k < cols; ++k) hb[(size_t)r * pcol + k] = host_f2bf(data[(size_t)r * cols + k]);
+        HIP_OK(h, hipMalloc(&t.p, hb.size() * 2));
+        HIP_OK(h, hipMemcpy(t.p, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+    } else {
+        const size_t bytes = (size_t)rows * cols * 4;
+        HIP_OK(h, hipMalloc(&t.p, bytes));
+        HIP_OK(h, hipMemcpy(t.p, data, bytes, hipMemcpyHostToDevice));
+    }
+    t.loaded = true;
+    h->finalized = false;
+    return 0;
+}
+
+int gitcap_finalize_weights(gitcap_t* h) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "finalize: null handle");
+    for (auto& kv : h->w)
+        if (!kv.second.loaded) return fail(h, GITCAP_ERR_STATE, "finalize: tensor '" + kv.first + "' was never loaded");
+    auto F = [&](const std::string& n) { return (const float*)h->w[n].p; };
+    auto Wt = [&](const std::string& n) { return (const bf16_t*)h->w[n].p; };
+    h->patch_w = Wt("enc.patch_w"); h->cls = F("enc.cls"); h->pos = F("enc.pos");
+    h->ln_pre_w = F("enc.ln_pre.w"); h->ln_pre_b = F("enc.ln_pre.b");
+    h->ln_post_w = F("enc.ln_post.w"); h->ln_post_b = F("enc.ln_post.b");
+    h->temporal = F("temporal");
+    h->vproj_w = Wt("vproj.w"); h->vproj_b = F("vproj.b"); h->vproj_lnw = F("vproj.ln.w"); h->vproj_lnb = F("vproj.ln.b");
+    h->word = F("txt.word"); h->tpos = F("txt.pos"); h->txt_lnw = F("txt.ln.w"); h->txt_lnb = F("txt.ln.b");
+    h->head_w = Wt("head.w"); h->head_b = F("head.b");
+    h->enc.resize(h->c.enc_layers);
+    for (int i = 0; i < h->c.enc_layers; ++i) {
+        const std::string p = "enc.L" + std::to_string(i) + ".";
+        EncLayer& L = h->enc[i];
+        L.ln1w = F(p + "ln1.w"); L.ln1b = F(p + "ln1.b"); L.ln2w = F(p + "ln2.w"); L.ln2b = F(p + "ln2.b");
+        L.qkvw = Wt(p + "qkv.w"); L.qkvb = F(p + "qkv.b"); L.projw = Wt(p + "proj.w"); L.projb = F(p + "proj.b");
+        L.fc1w = Wt(p + "fc1.w"); L.fc1b = F(p + "fc1.b"); L.fc2w = Wt(p + "fc2.w"); L.fc2b = F(p + "fc2.b");
+    }
+    h->dec.resize(h->c.dec_layers);
+    for (int i = 0; i < h->c.dec_layers; ++i) {
+        const std::string p = "dec.L" + std::to_string(i) + ".";
+        DecLayer& L = h->dec[i];
+        L.qkvw = Wt(p + "qkv.w"); L.qkvb = F(p + "qkv.b"); L.aow = Wt(p + "ao.w"); L.aob = F(p + "ao.b");
+        L.ln1w = F(p + "ln1.w"); L.ln1b = F(p + "ln1.b"); L.fc1w = Wt(p + "fc1.w"); L.fc1b = F(p + "fc1.b");
+        L.fc2w = Wt(p + "fc2.w"); L.fc2b = F(p + "fc2.b"); L.ln2w = F(p + "ln2.w"); L.ln2b = F(p + "ln2.b");
+    }
+    HIP_OK(h, hipDeviceSynchronize());
+    h->finalized = true;
+    return 0;
+}
+
+int gitcap_encode(gitcap_t* h, const float* frames, int B, int F, float* visual_out, void* stream) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "encode: null handle");
+    int rc = check_frames(h, frames, B, F);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const gitcap_config& c = h->c;
+    const int Dv = h->Dv, N = h->N, nf = B * F, rows = nf * N, Mp = pad_to(rows, 128);
+    const int P = nf * h->G * h->G, Pp = pad_to(P, 128);
+    h->have_image = false;
+
+    // patchify (conv k = stride = p, no bias) + CLS + position embedding, then ln_pre
+    HIP_OK(h, launch_im2col(frames, h->patches, nf, c.image_size, c.patch_size, h->Kp, s));
+    {
+        GemmArgs a{};
+        a.A = h->patches; a.lda = h->Kp; a.W = h->patch_w; a.bias = nullptr; a.M = Pp; a.N = Dv; a.K = h->Kp;
+        a.out = h->x; a.ldo = Dv; a.pos = h->pos; a.tokens_per_frame = N; a.patches_per_frame = h->G * h->G; a.valid_rows = P;
+        HIP_OK(h, launch_gemm(a, EPI_PATCH_F32, s));
+    }
+    HIP_OK(h, launch_cls_rows(h->x, h->cls, h->pos, nf, N, Dv, s));
+    if ((rc = ln(h, s, h->x, Dv, h->ln_pre_w, h->ln_pre_b, c.enc_ln_eps, rows, Dv, h->x, Dv, nullptr, 0))) return rc;
+
+    for (int i = 0; i < c.enc_layers; ++i) {
+        const EncLayer& L = h->enc[i];
+        if ((rc = ln(h, s, h->x, Dv, L.ln1w, L.ln1b, c.enc_ln_eps, rows, Dv, nullptr, 0, h->hb, Dv))) return rc;
+        if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, Dv, L.qkvw, L.qkvb, Mp, 3 * Dv, Dv, h->qkv, 3 * Dv))) return rc;
+        HIP_OK(h, launch_attn_full(h->qkv, h->ctx, nf, N, c.enc_heads, s));
+        if ((rc = gemm(h, s, EPI_BIAS_RESID_F32, h->ctx, Dv, L.projw, L.projb, Mp, Dv, Dv, h->x, Dv, h->x, Dv))) return rc;
+        if ((rc = ln(h, s, h->x, Dv, L.ln2w, L.ln2b, c.enc_ln_eps, rows, Dv, nullptr, 0, h->hb, Dv))) return rc;
+        if ((rc = gemm(h, s, EPI_BIAS_QGELU_BF16, h->hb, Dv, L.fc1w, L.fc1b, Mp, c.enc_ffn, Dv, h->ffn, c.enc_ffn))) return rc;
+        if ((rc = gemm(h, s, EPI_BIAS_RESID_F32, h->ffn, c.enc_ffn, L.fc2w, L.fc2b, Mp, Dv, c.enc_ffn, h->x, Dv, h->x, Dv))) return rc;
+    }
+    // ln_post (+ per-frame temporal embedding, model.py:380); frames of a clip are already
+    // adjacent rows, so the concat along tokens (model.py:382) is the identity on this layout
+    const float* addv = c.num_frames > 0 ? h->temporal : nullptr;
+    if ((rc = ln(h, s, h->x, Dv, h->ln_post_w, h->ln_post_b, c.enc_ln_eps, rows, Dv, h->visual, Dv, h->hb, Dv, addv, N, F))) return rc;
+    if (visual_out)
+        HIP_OK(h, hipMemcpyAsync(visual_out, h->visual, (size_t)rows * Dv * 4, hipMemcpyDeviceToDevice, s));
+    return image_prefix(h, B, F * N, s);
+}
+
+int gitcap_set_visual(gitcap_t* h, const float* visual, int B, int S_img, void* stream) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "set_visual: null handle");
+    if (!h->finalized) return fail(h, GITCAP_ERR_STATE, "weights not finalized");
+    if (!visual || B <= 0 || S_img <= 0) return fail(h, GITCAP_ERR_ARG, "set_visual: bad arguments");
+    if (B > h->c.max_batch || S_img > h->Smax) return fail(h, GITCAP_ERR_ARG, "set_visual: B/S_img exceed the sizes the handle was created for");
+    if (((uintptr_t)visual & 15) != 0) return fail(h, GITCAP_ERR_ARG, "set_visual: visual must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    h->have_image = false;
+    HIP_OK(h, launch_cast_bf16(visual, h->hb, (int64_t)B * S_img * h->Dv, s));
+    return image_prefix(h, B, S_img, s);
+}
+
+int gitcap_text_forward(gitcap_t* h, const int64_t* ids, int ld_ids, int rows, int beams, int t0, int T,
+                        float* logits_out, int all_positions, int64_t* argmax_out, int ld_argmax, void* stream) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "text_forward: null handle");
+    return text_forward(h, ids, ld_ids, rows, beams, t0, T, logits_out, all_positions, argmax_out, ld_argmax, nullptr, 0,
+                        (hipStream_t)stream);
+}
+
+int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, int stop, int64_t* ids_out,
+                  int32_t* steps_out, void* stream) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "greedy: null handle");
+    if (!ids_out || max_len <= 0) return fail(h, GITCAP_ERR_ARG, "greedy: bad arguments");
+    if (max_len > h->Tmax) return fail(h, GITCAP_ERR_ARG, "greedy: max_len exceeds max_text_len");
+    if (stop != GITCAP_STOP_NEVER && stop != GITCAP_STOP_ALL_SEP) return fail(h, GITCAP_ERR_ARG, "greedy: unknown stop rule");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = gitcap_encode(h, frames, B, F, nullptr, stream);
+    if (rc) return rc;
+    const int ld = max_len + 1;
+    // CLS start tokens [B,1] (model.py:171)
+    HIP_OK(h, launch_fill_i64(ids_out, ld, B, h->c.cls_token_id, s));
+    HIP_OK(h, hipMemsetAsync(h->sep_cnt, 0, ((size_t)h->Tmax + 1) * 4, s));
+    for (int t = 0; t < max_len; ++t) {
+        // forward on the sequence so far, argmax of the last position, append (model.py:173-182)
+        rc = text_forward(h, ids_out + t, ld, B, 1, t, 1, nullptr, 0, ids_out + t + 1, ld, h->sep_cnt, t, s);
+        if (rc) return rc;
+    }
+    if (steps_out) HIP_OK(h, launch_finish_steps(h->sep_cnt, B, max_len, stop, steps_out, s));
+    return 0;
+}
+
+int gitcap_reorder_rows(gitcap_t* h, const int32_t* src_rows, int rows, int t_len, void* stream) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "reorder_rows: null handle");
+    if (!src_rows || rows <= 0 || rows > h->R || t_len < 0 || t_len > h->Tmax)
+        return fail(h, GITCAP_ERR_ARG, "reorder_rows: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t layer = (size_t)h->R * h->Tmax * 3 * h->D;
+    for (int l = 0; l < h->c.dec_layers; ++l)
+        HIP_OK(h, launch_gather_txt_rows(h->kv_txt + l * layer, h->kv_txt2 + l * layer, src_rows, rows, t_len, h->Tmax, 3 * h->D, s));
+    std::swap(h->kv_txt, h->kv_txt2);
+    return 0;
+}
+
+int gitcap_workspace_bytes(const gitcap_t* h, int64_t* bytes) {
+    if (!h || !bytes) return GITCAP_ERR_ARG;
+    *bytes = h->ws_bytes;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// Launcher declarations for the gfx950 kernels behind libgitcap's C ABI.
+#pragma once
+#include "common.h"
+
+// ---- big-tile bf16 MFMA GEMM:  C[m][n] = sum_k A[m][k] * W[n][k]  (+ epilogue) -------------
+enum GemmEpi {
+    EPI_BIAS_BF16 = 0,        // out bf16 = acc + bias
+    EPI_BIAS_QGELU_BF16 = 1,  // out bf16 = quick_gelu(acc + bias)      (CLIP MLP)
+    EPI_BIAS_GELU_BF16 = 2,   // out bf16 = erf_gelu(acc + bias)        (BERT intermediate)
+    EPI_BIAS_RESID_F32 = 3,   // out f32  = acc + bias + resid          (out may alias resid)
+    EPI_BIAS_F32 = 4,         // out f32  = acc + bias
+    EPI_PATCH_F32 = 5         // out f32 row (frame*N + 1 + patch) = acc + pos[1+patch]
+};
+struct GemmArgs {
+    const bf16_t* A; int lda;     // activations [M][lda], M multiple of 128 (padded rows are junk)
+    const bf16_t* W;              // weights [N][K] (torch Linear layout), N multiple of 128
+    const float* bias;            // [N] or nullptr
+    int M, N, K;                  // K multiple of 64
+    void* out; int ldo;
+    const float* resid; int ldr;
+    const float* pos;             // EPI_PATCH: [tokens_per_frame][N]
+    int tokens_per_frame, patches_per_frame, valid_rows;
+};
+hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+
+// ---- skinny GEMM (M <= a few 16-row tiles): weight-streaming, split-K over the 4 waves -----
+enum SkinnyEpi {
+    SK_BIAS_BF16 = 0, SK_BIAS_GELU_BF16 = 1, SK_BIAS_RESID_F32 = 2, SK_BIAS_F32 = 3
+};
+struct SkinnyArgs {
+    const bf16_t* X; int ldx;     // [Mpad16][ldx] bf16 activations (row m at X + m*ldx)
+    const bf16_t* W;              // [Npad16][K]
+    const float* bias;            // [N]
+    int M, N, K;                  // M valid rows, N valid cols (weights padded to 16 rows), K % 128 == 0
+    void* out;                    // row m -> out + orow(m)*ldo, orow(m) = (m / T)*row_stride + row_off + m % T
+    int ldo, T, row_stride, row_off;
+    const float* resid; int ldr;  // f32 [M][ldr]
+};
+hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s);
+
+// ---- attention ---------------------------------------------------------------------------
+// Full (unmasked) self-attention over groups of S rows: qkv [G*S][3*W] bf16 (q | k | v, head h
+// at columns h*64), ctx [G*S][W] bf16.  Used for the ViT frames (S = N) and for the image
+// prefix of the decoder (S = F*N).
+hipError_t launch_attn_full(const bf16_t* qkv, bf16_t* ctx, int G, int S, int H, hipStream_t s);
+
+// Text rows: query (r, t0+j) attends image keys of clip r/beams and text keys 0..t0+j of row r.
+struct TextAttnArgs {
+    const bf16_t* kv_img;   // [B*S_img][3D] this layer
+    const bf16_t* kv_txt;   // [R][Tmax][3D] this layer (q at cols 0..D)
+    bf16_t* ctx;            // [R*T][D]
+    float* part;            // [R*T][H][nsplit][66] scratch
+    int rows, beams, t0, T, Tmax, S_img, H, D, nsplit;
+};
+hipError_t launch_attn_text(const TextAttnArgs& a, hipStream_t s);
+
+// ---- row ops -----------------------------------------------------------------------------
+struct LnArgs {
+    const float* x; int ldx;      // [rows][ldx]
+    const float* gamma; const float* beta; float eps;
+    int rows, D;
+    float* out_f32; int ld_f32;   // nullable
+    bf16_t* out_bf16; int ld_bf16;// nullable
+    const float* add_vec;         // nullable: out += add_vec[((row / add_div) % add_mod) * D + c]
+    int add_div, add_mod;
+};
+hipError_t launch_layernorm(const LnArgs& a, hipStream_t s);
+
+// frames [nf][3][H][W] f32 -> patches bf16 [nf*G*G][Kp] (k = c*p*p + py*p + px, zero padded)
+hipError_t launch_im2col(const float* frames, bf16_t* patches, int nf, int img, int p, int Kp, hipStream_t s);
+// x[frame*N + 0][:] = cls + pos[0]
+hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int nf, int N, int D, hipStream_t s);
+// f32 -> bf16 copy
+hipError_t launch_cast_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s);
+// text embedding + LN: row m=(r, j) -> token ids[r*ld_ids + j], position t0 + j
+hipError_t launch_embed_text(const int64_t* ids, int ld_ids, int rows, int T, int t0,
+                             const float* word, const float* pos, const float* gamma, const float* beta,
+                             float eps, int D, int vocab, float* x_f32, bf16_t* x_bf16, hipStream_t s);
+// argmax over [rows][V] (row stride ld) -> out[r*ld_out] (int64); lowest index wins ties.
+// If sep_cnt != nullptr: sep_cnt[step] += 1 for every row whose argmax is sep_id (zero it per call).
+hipError_t launch_argmax(const float* logits, int ld, int rows, int V, int64_t* out, int ld_out,
+                         int32_t* sep_flags, int step, int sep_id, hipStream_t s);
+hipError_t launch_finish_steps(const int32_t* sep_cnt, int rows, int max_len, int stop, int32_t* steps_out, hipStream_t s);
+hipError_t launch_fill_i64(int64_t* p, int ld, int rows, int64_t v, hipStream_t s);
+hipError_t launch_gather_txt_rows(const bf16_t* src, bf16_t* dst, const int32_t* src_rows, int rows,
+                                  int t_len, int Tmax, int width, hipStream_t s);

@@ -1,0 +1,294 @@
+// HBM-bound row kernels: LayerNorm (one wave per row, 16-byte vector loads), patch gather
+// (im2col of NCHW fp32 frames, coalesced 16-B reads along W), text embedding, argmax.
+#include "kernels.h"
+
+namespace {
+
+// ---- LayerNorm -------------------------------------------------------------------------------
+// One wave per row; lane holds NV float4 at columns 256*i + 4*lane (1 KiB contiguous per
+// wave-instruction).  Two-pass (mean, then centred variance) in registers, fp32 throughout.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const float* xr = a.x + (size_t)row * a.ldx;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < a.D) {
+            v[i] = *(const f32x4*)(xr + c);
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        } else {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(s) / (float)a.D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < a.D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)a.D + a.eps);
+    const float* addv = a.add_vec ? a.add_vec + (size_t)((row / a.add_div) % a.add_mod) * a.D : nullptr;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < a.D) {
+            const f32x4 g = *(const f32x4*)(a.gamma + c);
+            const f32x4 b = *(const f32x4*)(a.beta + c);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            if (addv) y += *(const f32x4*)(addv + c);
+            if (a.out_f32) *(f32x4*)(a.out_f32 + (size_t)row * a.ld_f32 + c) = y;
+            if (a.out_bf16) {
+                uint2 o;
+                o.x = pack_bf2(y[0], y[1]);
+                o.y = pack_bf2(y[2], y[3]);
+                *(uint2*)(a.out_bf16 + (size_t)row * a.ld_bf16 + c) = o;
+            }
+        }
+    }
+}
+
+// ---- im2col ----------------------------------------------------------------------------------
+// thread = 4 consecutive px of one (patch row, c, py): one 16-B fp32 read, one 8-B bf16 write.
+// p % 4 == 0 fast path; generic path handles p = 14 (ViT-L/14) with 2-element pieces.
+template <int VEC>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ frames, bf16_t* __restrict__ out,
+                                                     int nf, int img, int p, int Kp) {
+    const int G = img / p;
+    const int kvec = Kp / VEC;                                   // pieces per patch row (incl. zero pad)
+    const int64_t total = (int64_t)nf * G * G * kvec;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int kv = (int)(idx % kvec);
+    const int64_t prow = idx / kvec;                             // frame*G*G + gy*G + gx
+    const int k = kv * VEC;
+    bf16_t* o = out + prow * Kp + k;
+    if (k >= 3 * p * p) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = 0;
+        return;
+    }
+    const int gx = (int)(prow % G), gy = (int)((prow / G) % G);
+    const int64_t frame = prow / (G * G);
+    const int c = k / (p * p), rem = k - c * p * p, py = rem / p, px = rem - py * p;
+    const float* src = frames + ((frame * 3 + c) * img + (gy * p + py)) * (int64_t)img + gx * p + px;
+    if (VEC == 4) {
+        const f32x4 v = *(const f32x4*)src;
+        uint2 w;
+        w.x = pack_bf2(v[0], v[1]);
+        w.y = pack_bf2(v[2], v[3]);
+        *(uint2*)o = w;
+    } else {
+        *(unsigned*)o = pack_bf2(src[0], src[1]);
+    }
+}
+
+__global__ void cls_rows_kernel(float* x, const float* cls, const float* pos, int nf, int N, int D) {
+    const int f = blockIdx.x;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) x[(size_t)f * N * D + c] = cls[c] + pos[c];
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 v = *(const f32x4*)(in + i * 4);
+    uint2 w;
+    w.x = pack_bf2(v[0], v[1]);
+    w.y = pack_bf2(v[2], v[3]);
+    *(uint2*)(out + i * 4) = w;
+}
+
+// ---- text embedding + LayerNorm: one wave per (row, position) ----------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restrict__ ids, int ld_ids, int rows, int T,
+                                                         int t0, const float* __restrict__ word,
+                                                         const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, int D, int vocab,
+                                                         float* __restrict__ xf, bf16_t* __restrict__ xb) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= rows * T) return;
+    const int r = m / T, j = m - r * T;
+    int64_t tok = ids[(size_t)r * ld_ids + j];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);          // never index outside the table
+    const float* wr = word + (size_t)tok * D;
+    const float* pr = pos + (size_t)(t0 + j) * D;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+            v[i] = *(const f32x4*)(wr + c) + *(const f32x4*)(pr + c);
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        } else v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+            const f32x4 g = *(const f32x4*)(gamma + c);
+            const f32x4 b = *(const f32x4*)(beta + c);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            *(f32x4*)(xf + (size_t)m * D + c) = y;
+            uint2 o;
+            o.x = pack_bf2(y[0], y[1]);
+            o.y = pack_bf2(y[2], y[3]);
+            *(uint2*)(xb + (size_t)m * D + c) = o;
+        }
+    }
+}
+
+// ---- argmax: one block per row; lowest index wins ties (torch.argmax on CPU) -------------------
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int ld, int V,
+                                                     int64_t* __restrict__ out, int ld_out,
+                                                     int32_t* __restrict__ sep_cnt, int step, int sep_id) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float* p = logits + (size_t)r * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) {
+        const float v = p[i];
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(best, o);
+        const int i2 = __shfl_xor(bi, o);
+        if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+    }
+    if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        if (bi == 0x7fffffff) bi = 0;                               // all-NaN row: deterministic answer
+        out[(size_t)r * ld_out] = bi;
+        if (sep_cnt && bi == sep_id) atomicAdd(&sep_cnt[step], 1);
+    }
+}
+
+// steps_out = number of generated columns that are valid under the stop rule
+__global__ void finish_steps_kernel(const int32_t* sep_cnt, int rows, int max_len, int stop, int32_t* steps_out) {
+    int steps = max_len;
+    if (stop == 1) {
+        for (int t = 0; t < max_len; ++t)
+            if (sep_cnt[t] == rows) { steps = t + 1; break; }
+    }
+    *steps_out = steps;
+}
+
+__global__ void fill_i64_kernel(int64_t* p, int ld, int rows, int64_t v) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) p[(size_t)r * ld] = v;
+}
+
+// dst[r][t][:] = src[src_rows[r]][t][:] for t < t_len (text K/V rows, `width` bf16 per position)
+__global__ void gather_txt_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                       const int32_t* __restrict__ src_rows, int t_len, int Tmax, int width) {
+    const int r = blockIdx.x, sr = src_rows[r];
+    const int n8 = t_len * width / 8;
+    const uint4* s = (const uint4*)(src + (size_t)sr * Tmax * width);
+    uint4* d = (uint4*)(dst + (size_t)r * Tmax * width);
+    for (int i = threadIdx.x; i < n8; i += blockDim.x) d[i] = s[i];
+}
+
+}  // namespace
+
+hipError_t launch_layernorm(const LnArgs& a, hipStream_t s) {
+    if (a.rows <= 0 || a.D % 4 || a.D > 1024) return hipErrorInvalidValue;
+    const int grid = (a.rows + 3) / 4;
+    const int nv = (a.D + 255) / 256;
+    switch (nv) {
+        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, dim3(grid), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, dim3(grid), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, s, a); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_im2col(const float* frames, bf16_t* patches, int nf, int img, int p, int Kp, hipStream_t s) {
+    const int G = img / p;
+    if (p % 4 == 0 && img % 4 == 0) {
+        const int64_t total = (int64_t)nf * G * G * (Kp / 4);
+        hipLaunchKernelGGL(im2col_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frames, patches, nf, img, p, Kp);
+    } else if (p % 2 == 0) {
+        const int64_t total = (int64_t)nf * G * G * (Kp / 2);
+        hipLaunchKernelGGL(im2col_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frames, patches, nf, img, p, Kp);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int nf, int N, int D, hipStream_t s) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(nf), dim3(256), 0, s, x, cls, pos, nf, N, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_cast_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s) {
+    if (n % 4) return hipErrorInvalidValue;
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, in, out, n4);
+    return hipGetLastError();
+}
+
+hipError_t launch_embed_text(const int64_t* ids, int ld_ids, int rows, int T, int t0, const float* word,
+                             const float* pos, const float* gamma, const float* beta, float eps, int D, int vocab,
+                             float* x_f32, bf16_t* x_bf16, hipStream_t s) {
+    const int grid = (rows * T + 3) / 4;
+    const int nv = (D + 255) / 256;
+    if (nv == 1) hipLaunchKernelGGL(embed_text_kernel<1>, dim3(grid), dim3(256), 0, s, ids, ld_ids, rows, T, t0, word, pos, gamma, beta, eps, D, vocab, x_f32, x_bf16);
+    else if (nv == 2) hipLaunchKernelGGL(embed_text_kernel<2>, dim3(grid), dim3(256), 0, s, ids, ld_ids, rows, T, t0, word, pos, gamma, beta, eps, D, vocab, x_f32, x_bf16);
+    else if (nv == 3) hipLaunchKernelGGL(embed_text_kernel<3>, dim3(grid), dim3(256), 0, s, ids, ld_ids, rows, T, t0, word, pos, gamma, beta, eps, D, vocab, x_f32, x_bf16);
+    else hipLaunchKernelGGL(embed_text_kernel<4>, dim3(grid), dim3(256), 0, s, ids, ld_ids, rows, T, t0, word, pos, gamma, beta, eps, D, vocab, x_f32, x_bf16);
+    return hipGetLastError();
+}
+
+hipError_t launch_argmax(const float* logits, int ld, int rows, int V, int64_t* out, int ld_out,
+                         int32_t* sep_flags, int step, int sep_id, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, s, logits, ld, V, out, ld_out, sep_flags, step, sep_id);
+    return hipGetLastError();
+}
+
+hipError_t launch_finish_steps(const int32_t* sep_cnt, int rows, int max_len, int stop, int32_t* steps_out, hipStream_t s) {
+    hipLaunchKernelGGL(finish_steps_kernel, dim3(1), dim3(1), 0, s, sep_cnt, rows, max_len, stop, steps_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_i64(int64_t* p, int ld, int rows, int64_t v, hipStream_t s) {
+    hipLaunchKernelGGL(fill_i64_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, p, ld, rows, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_txt_rows(const bf16_t* src, bf16_t* dst, const int32_t* src_rows, int rows,
+                                  int t_len, int Tmax, int width, hipStream_t s) {
+    hipLaunchKernelGGL(gather_txt_rows_kernel, dim3(rows), dim3(256), 0, s, src, dst, src_rows, t_len, Tmax, width);
+    return hipGetLastError();
+}

@@ -1,0 +1,61 @@
+"""ctypes binding of libgitcap.so (include/gitcap.h).  There is no fallback: if the HIP
+library is missing or a call fails this module raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+from .config import CGitCapConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgitcap.so")
+
+# every symbol include/gitcap.h declares (tests/test_cabi.py checks the list against the header)
+SYMBOLS = {
+    "gitcap_abi_version": (c_int, []),
+    "gitcap_create": (c_int, [POINTER(CGitCapConfig), c_int, POINTER(c_void_p)]),
+    "gitcap_destroy": (None, [c_void_p]),
+    "gitcap_last_error": (c_char_p, [c_void_p]),
+    "gitcap_load_tensor": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
+    "gitcap_finalize_weights": (c_int, [c_void_p]),
+    "gitcap_encode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "gitcap_set_visual": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "gitcap_text_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "gitcap_greedy": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gitcap_reorder_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "gitcap_workspace_bytes": (c_int, [c_void_p, POINTER(c_int64)]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """dlopen libgitcap.so.  torch must already be imported so that the HIP runtime the
+    library binds to (SONAME libamdhip64.so.7) is the one torch loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C real-time-video-captioning_amd/csrc`). gitcap has no CPU/PyTorch fallback.")
+    import torch  # noqa: F401  (loads libamdhip64 first)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class GitcapError(RuntimeError):
+    pass
+
+
+def check(lib, handle, rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib.gitcap_last_error(handle)
+        raise GitcapError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")

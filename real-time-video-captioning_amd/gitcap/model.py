@@ -1,0 +1,277 @@
+"""Python host side of libgitcap: an ``nn.Module`` with the call surface the reference's
+callers use, so it can stand in for the model object of farazali7/real-time-video-captioning.
+
+Mirrored interface (reference file:line):
+  * ``greedy_decode(src, max_len)``           src/models/model.py:156-187, called by
+                                              src/real_time_inference.py:58, src/inference.py:51
+  * ``forward_image_enc(x)``                  src/models/model.py:114-133
+  * ``forward_decoder(y, memory)``            src/models/model.py:135-154
+  * ``forward(x, y)``                         src/models/model.py:105-112
+  * ``forward_output_logits(x, y)``           src/models/model.py:747-760 (teacher)
+  * ``beam_search(src, max_len, k)``          src/models/model.py:189-317 (signature)
+  * ``eval() / to() / load_state_dict()``     src/inference.py:38-40
+  * picklable                                 src/real_time_inference.py:8-9 (torch.load of a whole module)
+
+PyTorch is used for device buffers and the current HIP stream only; every FLOP of the path runs
+in the hand-written gfx950 kernels behind the C ABI (include/gitcap.h).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Mapping, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from .config import CGitCapConfig, GitCapConfig, git_base
+from . import weights as W
+
+STOP_NEVER, STOP_ALL_SEP = 0, 1
+
+
+def _rebuild(cfg_dict, weights, kwargs):
+    return GitCaptioner(GitCapConfig(**cfg_dict), weights, **kwargs)
+
+
+class GitCaptioner(nn.Module):
+    def __init__(self, cfg: Optional[GitCapConfig] = None, weights: Optional[Mapping[str, np.ndarray]] = None, *,
+                 device: str | torch.device = "cuda:0", max_batch: int = 16, max_frames: Optional[int] = None,
+                 max_text_len: int = 32, max_beams: int = 1, tokenizer=None, stop: str = "all_sep",
+                 # constructor kwargs of the reference student (model.py:55-57); only the ids/vocab matter here
+                 vocab_length: Optional[int] = None, cls_token_id: Optional[int] = None,
+                 sep_token_id: Optional[int] = None, **_ignored_student_kwargs):
+        super().__init__()
+        cfg = cfg or git_base()
+        over = {}
+        if vocab_length is not None:
+            over["vocab_size"] = int(vocab_length)
+        if cls_token_id is not None:
+            over["cls_token_id"] = int(cls_token_id)
+        if sep_token_id is not None:
+            over["sep_token_id"] = int(sep_token_id)
+        if over:
+            cfg = GitCapConfig(**{**cfg.to_dict(), **over})
+        cfg.validate()
+        self.cfg = cfg
+        self.tokenizer = tokenizer                      # attribute the reference's callers read (inference.py:43)
+        self.cls_token_id, self.sep_token_id = cfg.cls_token_id, cfg.sep_token_id
+        self.stop = stop
+        self._kw = dict(max_batch=max_batch, max_frames=max_frames, max_text_len=max_text_len,
+                        max_beams=max_beams, stop=stop)
+        self._dev = torch.device(device)
+        self._handle = None
+        self._weights: Optional[Dict[str, np.ndarray]] = None
+        self._last_memory = None
+        self._lib = _lib.load()                         # raises if libgitcap.so is missing
+        self._create()
+        if weights is not None:
+            self.load_state_dict(weights)
+
+    # ------------------------------------------------------------------ handle management
+    def _create(self):
+        if self._dev.type != "cuda":
+            raise _lib.GitcapError("gitcap runs on an AMD GPU only (no CPU path); got device %s" % self._dev)
+        if not torch.cuda.is_available():
+            raise _lib.GitcapError("no HIP device visible: gitcap has no CPU fallback")
+        kw = self._kw
+        self.max_batch = int(kw["max_batch"])
+        self.max_frames = int(kw["max_frames"] or max(1, self.cfg.num_frames))
+        self.max_text_len = int(kw["max_text_len"])
+        self.max_beams = int(kw["max_beams"])
+        cc = CGitCapConfig.from_config(self.cfg, self.max_batch, self.max_frames, self.max_text_len, self.max_beams)
+        h = ctypes.c_void_p()
+        idx = self._dev.index if self._dev.index is not None else torch.cuda.current_device()
+        self._dev = torch.device("cuda", idx)
+        rc = self._lib.gitcap_create(ctypes.byref(cc), idx, ctypes.byref(h))
+        _lib.check(self._lib, None, rc, "gitcap_create")
+        self._handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None):
+                self._lib.gitcap_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self._dev).cuda_stream)
+
+    def _call(self, name, *args):
+        rc = getattr(self._lib, name)(self._handle, *args)
+        _lib.check(self._lib, self._handle, rc, name)
+
+    # ------------------------------------------------------------------ nn.Module surface
+    def to(self, *args, **kwargs):
+        dev = kwargs.get("device", args[0] if args else None)
+        if isinstance(dev, (str, torch.device)):
+            dev = torch.device(dev)
+            if dev.type != "cuda":
+                raise _lib.GitcapError("gitcap has no CPU path; .to(%s) refused" % dev)
+            idx = dev.index if dev.index is not None else torch.cuda.current_device()
+            if idx != self._dev.index:
+                self._lib.gitcap_destroy(self._handle)
+                self._dev = torch.device("cuda", idx)
+                self._create()
+                if self._weights is not None:
+                    self._upload(self._weights)
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))
+
+    def state_dict(self, *a, **k):
+        return {n: torch.from_numpy(v) for n, v in (self._weights or {}).items()}
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Accepts canonical names (gitcap/weights.py), a transformers GitForCausalLM state dict or the
+        MS GenerativeImage2Text checkpoint layout the reference loads (model.py:736-738)."""
+        keys = state_dict.keys()
+        if "enc.patch_w" in keys:
+            w = {k: np.ascontiguousarray(v.detach().cpu().float().numpy() if hasattr(v, "detach") else v,
+                                         dtype=np.float32) for k, v in state_dict.items()}
+            W.check_shapes(self.cfg, w)
+        elif any(k.startswith("git.") for k in keys):
+            w = W.from_hf_state_dict(self.cfg, state_dict)
+        elif any(k.startswith("image_encoder.") for k in keys):
+            w = W.from_ms_state_dict(self.cfg, state_dict)
+        else:
+            raise KeyError("unrecognised checkpoint layout (expected canonical, HF-GIT or MS-GIT keys)")
+        self._upload(w)
+        self._weights = w
+        return self
+
+    def _upload(self, w: Mapping[str, np.ndarray]):
+        with torch.cuda.device(self._dev):
+            for name in W.canonical_shapes(self.cfg):
+                arr = np.ascontiguousarray(w[name], dtype=np.float32)
+                shape = (ctypes.c_int64 * arr.ndim)(*arr.shape)
+                self._call("gitcap_load_tensor", name.encode(), arr.ctypes.data_as(ctypes.c_void_p), shape, arr.ndim)
+            self._call("gitcap_finalize_weights")
+
+    def __reduce__(self):
+        kw = dict(self._kw)
+        kw["device"] = str(self._dev)
+        return _rebuild, (self.cfg.to_dict(), self._weights, kw)
+
+    # ------------------------------------------------------------------ helpers
+    def _frames(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() == 4:                                  # [B,3,H,W] single image -> one frame
+            x = x.unsqueeze(1)
+        if x.dim() != 5 or x.shape[2] != 3 or x.shape[3] != self.cfg.image_size or x.shape[4] != self.cfg.image_size:
+            raise ValueError(f"expected frames [B,F,3,{self.cfg.image_size},{self.cfg.image_size}], got {tuple(x.shape)}")
+        if x.shape[1] > self.max_frames:
+            raise ValueError(f"{x.shape[1]} frames per clip > max_frames={self.max_frames}")
+        x = x.to(device=self._dev, dtype=torch.float32).contiguous()
+        if x.data_ptr() % 16:
+            x = x.clone()
+        return x
+
+    def _ids(self, y: torch.Tensor) -> torch.Tensor:
+        return y.to(device=self._dev, dtype=torch.int64).contiguous()
+
+    # ------------------------------------------------------------------ reference API
+    @torch.no_grad()
+    def forward_image_enc(self, x: torch.Tensor):
+        """-> ([], memory) with memory = visual features [B, F*N, Dv] (ln_post + temporal embedding,
+        frames concatenated along tokens, model.py:378-382).  Also leaves the decoder's image K/V
+        in the handle."""
+        fr = self._frames(x)
+        B, F = fr.shape[:2]
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} > max_batch={self.max_batch} (use greedy_decode for automatic chunking)")
+        vis = torch.empty((B, F * self.cfg.tokens_per_frame, self.cfg.enc_width), dtype=torch.float32, device=self._dev)
+        with torch.cuda.device(self._dev):
+            self._call("gitcap_encode", ctypes.c_void_p(fr.data_ptr()), B, F, ctypes.c_void_p(vis.data_ptr()), self._stream())
+        self._last_memory = (vis.data_ptr(), vis._version, tuple(vis.shape))
+        return [], vis
+
+    @torch.no_grad()
+    def forward_decoder(self, y: torch.Tensor, memory: torch.Tensor) -> torch.Tensor:
+        """Teacher-forced logits [B,T,V] for token prefixes y [B,T] given `memory` from
+        forward_image_enc (block mask: text->image full, text->text causal)."""
+        ids = self._ids(y)
+        B, T = ids.shape
+        with torch.cuda.device(self._dev):
+            if self._last_memory != (memory.data_ptr(), memory._version, tuple(memory.shape)):
+                mem = memory.to(device=self._dev, dtype=torch.float32).contiguous()
+                self._call("gitcap_set_visual", ctypes.c_void_p(mem.data_ptr()), mem.shape[0], mem.shape[1], self._stream())
+                self._last_memory = (memory.data_ptr(), memory._version, tuple(memory.shape))
+            logits = torch.empty((B, T, self.cfg.vocab_size), dtype=torch.float32, device=self._dev)
+            self._call("gitcap_text_forward", ctypes.c_void_p(ids.data_ptr()), T, B, 1, 0, T,
+                       ctypes.c_void_p(logits.data_ptr()), 1, None, 0, self._stream())
+        return logits
+
+    def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        _, memory = self.forward_image_enc(x)
+        return self.forward_decoder(y, memory)
+
+    @torch.no_grad()
+    def forward_output_logits(self, x: torch.Tensor, y: torch.Tensor):
+        """Teacher API (model.py:747-760): per clip lists of logits [1,T,V] and visual features
+        [1,F*N,Dv]; computed as ONE batch instead of the reference's clip-by-clip loop (:752-759).
+        Per-layer hidden states (third list) are not exported by the kernels: returned empty."""
+        _, vis = self.forward_image_enc(x)
+        logits = self.forward_decoder(y, vis)
+        return [l[None] for l in logits], [v[None] for v in vis], []
+
+    @torch.no_grad()
+    def greedy_decode(self, src: torch.Tensor, max_len: int = 10, stop: Optional[str] = None) -> torch.Tensor:
+        """CLS-prefixed greedy ids [B, 1+steps] (model.py:156-187).  stop='all_sep' is the
+        reference rule (break when every row emits SEP in the same step, :184); 'never' always
+        runs max_len steps.  The loop runs on the device without per-step host syncs; the
+        truncation the reference's `break` implies is applied afterwards."""
+        stop = stop or self.stop
+        mode = {"all_sep": STOP_ALL_SEP, "never": STOP_NEVER}[stop]
+        if max_len > self.max_text_len:
+            raise ValueError(f"max_len {max_len} > max_text_len={self.max_text_len} the handle was created for")
+        fr = self._frames(src)
+        B, F = fr.shape[:2]
+        outs, steps_all = [], []
+        with torch.cuda.device(self._dev):
+            for b0 in range(0, B, self.max_batch):
+                chunk = fr[b0:b0 + self.max_batch]
+                ids = torch.empty((chunk.shape[0], max_len + 1), dtype=torch.int64, device=self._dev)
+                steps = torch.zeros((1,), dtype=torch.int32, device=self._dev)
+                self._call("gitcap_greedy", ctypes.c_void_p(chunk.data_ptr()), chunk.shape[0], F, max_len, mode,
+                           ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(steps.data_ptr()), self._stream())
+                outs.append(ids)
+                steps_all.append(steps)
+        self._last_memory = None
+        ids = torch.cat(outs, 0)
+        if mode == STOP_ALL_SEP:
+            if len(outs) == 1:
+                n = int(steps_all[0].item())
+            else:   # the rule is over the WHOLE batch: first step at which every row emitted SEP
+                all_sep = (ids[:, 1:] == self.sep_token_id).all(dim=0)
+                nz = torch.nonzero(all_sep)
+                n = int(nz[0].item()) + 1 if nz.numel() else max_len
+            ids = ids[:, :1 + n]
+        return ids.to(src.device) if src.device != ids.device else ids
+
+    generate = greedy_decode      # the name BASELINE.json's north_star uses for this entry point
+
+    @torch.no_grad()
+    def step_logits(self, ids_last: torch.Tensor, t: int, beams: int = 1) -> torch.Tensor:
+        """One KV-cached decoding step = `scores = step(input_ids)` of model.py:519: ids_last [rows]
+        is the token at text position t of every row; returns fp32 logits [rows, V]."""
+        ids = self._ids(ids_last).view(-1, 1)
+        rows = ids.shape[0]
+        logits = torch.empty((rows, self.cfg.vocab_size), dtype=torch.float32, device=self._dev)
+        with torch.cuda.device(self._dev):
+            self._call("gitcap_text_forward", ctypes.c_void_p(ids.data_ptr()), 1, rows, beams, t, 1,
+                       ctypes.c_void_p(logits.data_ptr()), 0, None, 0, self._stream())
+        return logits
+
+    def reorder_rows(self, src_rows: torch.Tensor, t_len: int):
+        """Beam reorder of the text K/V cache (what model.py:623-634 sketches in comments)."""
+        idx = src_rows.to(device=self._dev, dtype=torch.int32).contiguous()
+        with torch.cuda.device(self._dev):
+            self._call("gitcap_reorder_rows", ctypes.c_void_p(idx.data_ptr()), idx.numel(), t_len, self._stream())
+
+    def workspace_bytes(self) -> int:
+        n = ctypes.c_int64()
+        self._lib.gitcap_workspace_bytes(self._handle, ctypes.byref(n))
+        return n.value

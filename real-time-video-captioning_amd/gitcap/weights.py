@@ -1,0 +1,267 @@
+"""Canonical weight names for the GIT captioning path, synthetic initialisation and
+importers from the two public checkpoint layouts.
+
+Canonical layout (all tensors row-major, Linear weights are ``[out, in]`` like torch.nn.Linear):
+
+  enc.patch_w [Dv, 3*p*p]      conv patch-embed weight, flattened (c, py, px); no bias
+  enc.cls [Dv]  enc.pos [N, Dv]  enc.ln_pre.{w,b}  enc.ln_post.{w,b}
+  enc.L{i}.ln1.{w,b}  enc.L{i}.qkv.{w [3Dv,Dv], b [3Dv]}  enc.L{i}.proj.{w,b}
+  enc.L{i}.ln2.{w,b}  enc.L{i}.fc1.{w,b}  enc.L{i}.fc2.{w,b}
+  temporal [F, Dv]             img_temperal_embedding (model.py:380); absent rows = 0
+  vproj.{w [D,Dv], b}  vproj.ln.{w,b}          'linearLn' visual projection (model.py:699)
+  txt.word [V, D]  txt.pos [P, D]  txt.ln.{w,b}
+  dec.L{i}.qkv.{w [3D,D], b}  dec.L{i}.ao.{w,b}  dec.L{i}.ln1.{w,b}
+  dec.L{i}.fc1.{w,b}  dec.L{i}.fc2.{w,b}  dec.L{i}.ln2.{w,b}
+  head.{w [V, D], b [V]}
+
+The reference loads the MS checkpoint with ``torch.load(path)['model']``
+(/root/reference/src/models/model.py:736-738); ``from_ms_state_dict`` accepts that dict,
+``from_hf_state_dict`` accepts a ``transformers`` GitForCausalLM state dict.
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from typing import Dict, Mapping
+
+import numpy as np
+
+from .config import GitCapConfig
+
+
+def canonical_shapes(cfg: GitCapConfig) -> "OrderedDict[str, tuple]":
+    Dv, D, V = cfg.enc_width, cfg.dec_width, cfg.vocab_size
+    N, P = cfg.tokens_per_frame, cfg.max_text_pos
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    s["enc.patch_w"] = (Dv, cfg.patch_dim)
+    s["enc.cls"] = (Dv,)
+    s["enc.pos"] = (N, Dv)
+    for nm in ("enc.ln_pre", "enc.ln_post"):
+        s[nm + ".w"] = (Dv,)
+        s[nm + ".b"] = (Dv,)
+    for i in range(cfg.enc_layers):
+        p = f"enc.L{i}."
+        s[p + "ln1.w"] = (Dv,); s[p + "ln1.b"] = (Dv,)
+        s[p + "qkv.w"] = (3 * Dv, Dv); s[p + "qkv.b"] = (3 * Dv,)
+        s[p + "proj.w"] = (Dv, Dv); s[p + "proj.b"] = (Dv,)
+        s[p + "ln2.w"] = (Dv,); s[p + "ln2.b"] = (Dv,)
+        s[p + "fc1.w"] = (cfg.enc_ffn, Dv); s[p + "fc1.b"] = (cfg.enc_ffn,)
+        s[p + "fc2.w"] = (Dv, cfg.enc_ffn); s[p + "fc2.b"] = (Dv,)
+    s["temporal"] = (max(1, cfg.num_frames), Dv)
+    s["vproj.w"] = (D, Dv); s["vproj.b"] = (D,)
+    s["vproj.ln.w"] = (D,); s["vproj.ln.b"] = (D,)
+    s["txt.word"] = (V, D); s["txt.pos"] = (P, D)
+    s["txt.ln.w"] = (D,); s["txt.ln.b"] = (D,)
+    for i in range(cfg.dec_layers):
+        p = f"dec.L{i}."
+        s[p + "qkv.w"] = (3 * D, D); s[p + "qkv.b"] = (3 * D,)
+        s[p + "ao.w"] = (D, D); s[p + "ao.b"] = (D,)
+        s[p + "ln1.w"] = (D,); s[p + "ln1.b"] = (D,)
+        s[p + "fc1.w"] = (cfg.dec_ffn, D); s[p + "fc1.b"] = (cfg.dec_ffn,)
+        s[p + "fc2.w"] = (D, cfg.dec_ffn); s[p + "fc2.b"] = (D,)
+        s[p + "ln2.w"] = (D,); s[p + "ln2.b"] = (D,)
+    s["head.w"] = (V, D); s["head.b"] = (V,)
+    return s
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    # one independent PCG64 stream per tensor: results do not depend on iteration order
+    return np.random.default_rng([seed, zlib.crc32(name.encode())])
+
+
+def synthetic_weights(cfg: GitCapConfig, seed: int = 0, head_gain: float = 4.0) -> Dict[str, np.ndarray]:
+    """Seeded random weights (numpy PCG64, bit-stable across machines).
+
+    Linear weights ~ N(0, gain^2/fan_in) so activations stay O(1) through every layer;
+    q/k rows get a larger gain so softmax rows are peaked rather than uniform; LayerNorm
+    scales/shifts and biases are perturbed so that a dropped bias or a swapped w/b shows up.
+    ``head_gain`` sets the spread of the vocabulary logits (std ~ head_gain).
+    """
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in canonical_shapes(cfg).items():
+        g = _rng(seed, name)
+        if name.endswith("ln1.w") or name.endswith("ln2.w") or name.endswith("ln.w") \
+                or name.endswith("ln_pre.w") or name.endswith("ln_post.w"):
+            t = 1.0 + 0.1 * g.standard_normal(shape)
+        elif name.endswith(".b"):
+            t = 0.05 * g.standard_normal(shape)
+        elif name in ("enc.cls", "enc.pos", "temporal", "txt.pos"):
+            t = 0.3 * g.standard_normal(shape)
+        elif name == "txt.word":
+            t = g.standard_normal(shape)
+        elif name == "head.w":
+            t = head_gain / np.sqrt(shape[1]) * g.standard_normal(shape)
+        elif name.endswith("qkv.w"):
+            t = g.standard_normal(shape) / np.sqrt(shape[1])
+            d = shape[0] // 3
+            t[: 2 * d] *= 1.6          # q and k
+            t[2 * d:] *= 0.8           # v
+        else:  # generic linear / conv weight
+            t = 0.8 / np.sqrt(shape[1]) * g.standard_normal(shape)
+        out[name] = np.ascontiguousarray(t, dtype=np.float32)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Importers
+# --------------------------------------------------------------------------------------
+def _np(t) -> np.ndarray:
+    if hasattr(t, "detach"):
+        t = t.detach().to("cpu").float().numpy()
+    return np.ascontiguousarray(t, dtype=np.float32)
+
+
+def from_hf_state_dict(cfg: GitCapConfig, sd: Mapping[str, object]) -> Dict[str, np.ndarray]:
+    """transformers.GitForCausalLM state-dict -> canonical (q/k/v fused into one matrix)."""
+    g = lambda k: _np(sd[k])
+    w: Dict[str, np.ndarray] = {}
+    ve = "git.image_encoder.vision_model."
+    w["enc.patch_w"] = g(ve + "embeddings.patch_embedding.weight").reshape(cfg.enc_width, -1)
+    w["enc.cls"] = g(ve + "embeddings.class_embedding")
+    w["enc.pos"] = g(ve + "embeddings.position_embedding.weight")
+    w["enc.ln_pre.w"] = g(ve + "pre_layrnorm.weight"); w["enc.ln_pre.b"] = g(ve + "pre_layrnorm.bias")
+    w["enc.ln_post.w"] = g(ve + "post_layernorm.weight"); w["enc.ln_post.b"] = g(ve + "post_layernorm.bias")
+    for i in range(cfg.enc_layers):
+        s, p = ve + f"encoder.layers.{i}.", f"enc.L{i}."
+        w[p + "ln1.w"] = g(s + "layer_norm1.weight"); w[p + "ln1.b"] = g(s + "layer_norm1.bias")
+        w[p + "qkv.w"] = np.concatenate([g(s + f"self_attn.{n}_proj.weight") for n in "qkv"], 0)
+        w[p + "qkv.b"] = np.concatenate([g(s + f"self_attn.{n}_proj.bias") for n in "qkv"], 0)
+        w[p + "proj.w"] = g(s + "self_attn.out_proj.weight"); w[p + "proj.b"] = g(s + "self_attn.out_proj.bias")
+        w[p + "ln2.w"] = g(s + "layer_norm2.weight"); w[p + "ln2.b"] = g(s + "layer_norm2.bias")
+        w[p + "fc1.w"] = g(s + "mlp.fc1.weight"); w[p + "fc1.b"] = g(s + "mlp.fc1.bias")
+        w[p + "fc2.w"] = g(s + "mlp.fc2.weight"); w[p + "fc2.b"] = g(s + "mlp.fc2.bias")
+    F = max(1, cfg.num_frames)
+    temporal = np.zeros((F, cfg.enc_width), np.float32)
+    for f in range(F):
+        k = f"git.img_temporal_embedding.{f}"
+        if k in sd:
+            temporal[f] = g(k).reshape(-1)
+    w["temporal"] = temporal
+    w["vproj.w"] = g("git.visual_projection.visual_projection.0.weight")
+    w["vproj.b"] = g("git.visual_projection.visual_projection.0.bias")
+    w["vproj.ln.w"] = g("git.visual_projection.visual_projection.1.weight")
+    w["vproj.ln.b"] = g("git.visual_projection.visual_projection.1.bias")
+    w["txt.word"] = g("git.embeddings.word_embeddings.weight")
+    w["txt.pos"] = g("git.embeddings.position_embeddings.weight")
+    w["txt.ln.w"] = g("git.embeddings.LayerNorm.weight"); w["txt.ln.b"] = g("git.embeddings.LayerNorm.bias")
+    for i in range(cfg.dec_layers):
+        s, p = f"git.encoder.layer.{i}.", f"dec.L{i}."
+        w[p + "qkv.w"] = np.concatenate([g(s + f"attention.self.{n}.weight") for n in ("query", "key", "value")], 0)
+        w[p + "qkv.b"] = np.concatenate([g(s + f"attention.self.{n}.bias") for n in ("query", "key", "value")], 0)
+        w[p + "ao.w"] = g(s + "attention.output.dense.weight"); w[p + "ao.b"] = g(s + "attention.output.dense.bias")
+        w[p + "ln1.w"] = g(s + "attention.output.LayerNorm.weight"); w[p + "ln1.b"] = g(s + "attention.output.LayerNorm.bias")
+        w[p + "fc1.w"] = g(s + "intermediate.dense.weight"); w[p + "fc1.b"] = g(s + "intermediate.dense.bias")
+        w[p + "fc2.w"] = g(s + "output.dense.weight"); w[p + "fc2.b"] = g(s + "output.dense.bias")
+        w[p + "ln2.w"] = g(s + "output.LayerNorm.weight"); w[p + "ln2.b"] = g(s + "output.LayerNorm.bias")
+    w["head.w"] = g("output.weight"); w["head.b"] = g("output.bias")
+    check_shapes(cfg, w)
+    return w
+
+
+def to_hf_state_dict(cfg: GitCapConfig, w: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Inverse of from_hf_state_dict (used by oracle/gen_golden_hf.py to load our synthetic
+    weights into the transformers implementation)."""
+    sd: Dict[str, np.ndarray] = {}
+    ve = "git.image_encoder.vision_model."
+    p_ = cfg.patch_size
+    sd[ve + "embeddings.patch_embedding.weight"] = w["enc.patch_w"].reshape(cfg.enc_width, 3, p_, p_)
+    sd[ve + "embeddings.class_embedding"] = w["enc.cls"]
+    sd[ve + "embeddings.position_embedding.weight"] = w["enc.pos"]
+    sd[ve + "pre_layrnorm.weight"] = w["enc.ln_pre.w"]; sd[ve + "pre_layrnorm.bias"] = w["enc.ln_pre.b"]
+    sd[ve + "post_layernorm.weight"] = w["enc.ln_post.w"]; sd[ve + "post_layernorm.bias"] = w["enc.ln_post.b"]
+    Dv, D = cfg.enc_width, cfg.dec_width
+    for i in range(cfg.enc_layers):
+        s, p = ve + f"encoder.layers.{i}.", f"enc.L{i}."
+        sd[s + "layer_norm1.weight"] = w[p + "ln1.w"]; sd[s + "layer_norm1.bias"] = w[p + "ln1.b"]
+        for j, n in enumerate("qkv"):
+            sd[s + f"self_attn.{n}_proj.weight"] = w[p + "qkv.w"][j * Dv:(j + 1) * Dv]
+            sd[s + f"self_attn.{n}_proj.bias"] = w[p + "qkv.b"][j * Dv:(j + 1) * Dv]
+        sd[s + "self_attn.out_proj.weight"] = w[p + "proj.w"]; sd[s + "self_attn.out_proj.bias"] = w[p + "proj.b"]
+        sd[s + "layer_norm2.weight"] = w[p + "ln2.w"]; sd[s + "layer_norm2.bias"] = w[p + "ln2.b"]
+        sd[s + "mlp.fc1.weight"] = w[p + "fc1.w"]; sd[s + "mlp.fc1.bias"] = w[p + "fc1.b"]
+        sd[s + "mlp.fc2.weight"] = w[p + "fc2.w"]; sd[s + "mlp.fc2.bias"] = w[p + "fc2.b"]
+    if cfg.num_frames:
+        for f in range(cfg.num_frames):
+            sd[f"git.img_temporal_embedding.{f}"] = w["temporal"][f].reshape(1, 1, Dv)
+    sd["git.visual_projection.visual_projection.0.weight"] = w["vproj.w"]
+    sd["git.visual_projection.visual_projection.0.bias"] = w["vproj.b"]
+    sd["git.visual_projection.visual_projection.1.weight"] = w["vproj.ln.w"]
+    sd["git.visual_projection.visual_projection.1.bias"] = w["vproj.ln.b"]
+    sd["git.embeddings.word_embeddings.weight"] = w["txt.word"]
+    sd["git.embeddings.position_embeddings.weight"] = w["txt.pos"]
+    sd["git.embeddings.LayerNorm.weight"] = w["txt.ln.w"]; sd["git.embeddings.LayerNorm.bias"] = w["txt.ln.b"]
+    for i in range(cfg.dec_layers):
+        s, p = f"git.encoder.layer.{i}.", f"dec.L{i}."
+        for j, n in enumerate(("query", "key", "value")):
+            sd[s + f"attention.self.{n}.weight"] = w[p + "qkv.w"][j * D:(j + 1) * D]
+            sd[s + f"attention.self.{n}.bias"] = w[p + "qkv.b"][j * D:(j + 1) * D]
+        sd[s + "attention.output.dense.weight"] = w[p + "ao.w"]; sd[s + "attention.output.dense.bias"] = w[p + "ao.b"]
+        sd[s + "attention.output.LayerNorm.weight"] = w[p + "ln1.w"]; sd[s + "attention.output.LayerNorm.bias"] = w[p + "ln1.b"]
+        sd[s + "intermediate.dense.weight"] = w[p + "fc1.w"]; sd[s + "intermediate.dense.bias"] = w[p + "fc1.b"]
+        sd[s + "output.dense.weight"] = w[p + "fc2.w"]; sd[s + "output.dense.bias"] = w[p + "fc2.b"]
+        sd[s + "output.LayerNorm.weight"] = w[p + "ln2.w"]; sd[s + "output.LayerNorm.bias"] = w[p + "ln2.b"]
+    sd["output.weight"] = w["head.w"]; sd["output.bias"] = w["head.b"]
+    return sd
+
+
+def from_ms_state_dict(cfg: GitCapConfig, sd: Mapping[str, object]) -> Dict[str, np.ndarray]:
+    """microsoft/GenerativeImage2Text checkpoint (``ckpt['model']``, model.py:736-738) -> canonical.
+
+    Key layout of that package (OpenAI-CLIP visual tower + BERT encoder used as decoder):
+    ``image_encoder.{conv1,class_embedding,positional_embedding,ln_pre,ln_post}``,
+    ``image_encoder.transformer.resblocks.N.{ln_1,attn.in_proj_*,attn.out_proj,ln_2,mlp.c_fc,mlp.c_proj}``
+    (resblocks are what model.py:847 hooks), ``img_temperal_embedding.N`` (model.py:380),
+    ``textual.visual_projection.{0,1}``, ``textual.embedding.{words,positions,layer_norm}``,
+    ``textual.transformer.encoder.layer.N.*`` (hooked at model.py:857), ``textual.output``.
+    CLIP's fused ``in_proj`` is already [3Dv, Dv] in q,k,v order, which is the canonical layout.
+    """
+    g = lambda k: _np(sd[k])
+    w: Dict[str, np.ndarray] = {}
+    ie = "image_encoder."
+    w["enc.patch_w"] = g(ie + "conv1.weight").reshape(cfg.enc_width, -1)
+    w["enc.cls"] = g(ie + "class_embedding")
+    w["enc.pos"] = g(ie + "positional_embedding")
+    w["enc.ln_pre.w"] = g(ie + "ln_pre.weight"); w["enc.ln_pre.b"] = g(ie + "ln_pre.bias")
+    w["enc.ln_post.w"] = g(ie + "ln_post.weight"); w["enc.ln_post.b"] = g(ie + "ln_post.bias")
+    for i in range(cfg.enc_layers):
+        s, p = ie + f"transformer.resblocks.{i}.", f"enc.L{i}."
+        w[p + "ln1.w"] = g(s + "ln_1.weight"); w[p + "ln1.b"] = g(s + "ln_1.bias")
+        w[p + "qkv.w"] = g(s + "attn.in_proj_weight"); w[p + "qkv.b"] = g(s + "attn.in_proj_bias")
+        w[p + "proj.w"] = g(s + "attn.out_proj.weight"); w[p + "proj.b"] = g(s + "attn.out_proj.bias")
+        w[p + "ln2.w"] = g(s + "ln_2.weight"); w[p + "ln2.b"] = g(s + "ln_2.bias")
+        w[p + "fc1.w"] = g(s + "mlp.c_fc.weight"); w[p + "fc1.b"] = g(s + "mlp.c_fc.bias")
+        w[p + "fc2.w"] = g(s + "mlp.c_proj.weight"); w[p + "fc2.b"] = g(s + "mlp.c_proj.bias")
+    F = max(1, cfg.num_frames)
+    temporal = np.zeros((F, cfg.enc_width), np.float32)
+    for f in range(F):
+        k = f"img_temperal_embedding.{f}"
+        if k in sd:
+            temporal[f] = g(k).reshape(-1)
+    w["temporal"] = temporal
+    t = "textual."
+    w["vproj.w"] = g(t + "visual_projection.0.weight"); w["vproj.b"] = g(t + "visual_projection.0.bias")
+    w["vproj.ln.w"] = g(t + "visual_projection.1.weight"); w["vproj.ln.b"] = g(t + "visual_projection.1.bias")
+    w["txt.word"] = g(t + "embedding.words.weight"); w["txt.pos"] = g(t + "embedding.positions.weight")
+    w["txt.ln.w"] = g(t + "embedding.layer_norm.weight"); w["txt.ln.b"] = g(t + "embedding.layer_norm.bias")
+    for i in range(cfg.dec_layers):
+        s, p = t + f"transformer.encoder.layer.{i}.", f"dec.L{i}."
+        w[p + "qkv.w"] = np.concatenate([g(s + f"attention.self.{n}.weight") for n in ("query", "key", "value")], 0)
+        w[p + "qkv.b"] = np.concatenate([g(s + f"attention.self.{n}.bias") for n in ("query", "key", "value")], 0)
+        w[p + "ao.w"] = g(s + "attention.output.dense.weight"); w[p + "ao.b"] = g(s + "attention.output.dense.bias")
+        w[p + "ln1.w"] = g(s + "attention.output.LayerNorm.weight"); w[p + "ln1.b"] = g(s + "attention.output.LayerNorm.bias")
+        w[p + "fc1.w"] = g(s + "intermediate.dense.weight"); w[p + "fc1.b"] = g(s + "intermediate.dense.bias")
+        w[p + "fc2.w"] = g(s + "output.dense.weight"); w[p + "fc2.b"] = g(s + "output.dense.bias")
+        w[p + "ln2.w"] = g(s + "output.LayerNorm.weight"); w[p + "ln2.b"] = g(s + "output.LayerNorm.bias")
+    w["head.w"] = g(t + "output.weight"); w["head.b"] = g(t + "output.bias")
+    check_shapes(cfg, w)
+    return w
+
+
+def check_shapes(cfg: GitCapConfig, w: Mapping[str, np.ndarray]) -> None:
+    want = canonical_shapes(cfg)
+    missing = [k for k in want if k not in w]
+    if missing:
+        raise KeyError(f"missing weights: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+    for k, shp in want.items():
+        if tuple(w[k].shape) != tuple(shp):
+            raise ValueError(f"weight {k}: shape {tuple(w[k].shape)} != expected {tuple(shp)}")
