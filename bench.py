@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""Headline benchmark: captions/s (+ p50 step latency) of the GIT caption hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): per GPU a batch of
+16 synthetic 6-frame 224x224 clips, GIT-base (ViT-B/16 encoder + 6-layer decoder), bf16 MFMA GEMMs,
+20-token greedy decode with EOS disabled so every caption costs the same work.  One "step" = one
+pass of the whole path (frames resident in HBM -> caption ids) over that batch.  With N > 1 GPUs
+the clips shard embarrassingly (one process per GPU, full weight replica) and the only collective
+is an RCCL all_gather of the caption ids (int64 [16, 21] per rank) at the end of every step.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "real-time-video-captioning_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np      # noqa: E402
+import torch            # noqa: E402
+
+CLIPS_PER_GPU, FRAMES, TOKENS = 16, 6, 20
+GFLOP_PER_CAPTION = 341.5          # SURVEY.md par. 8(d): GIT-base F=6 T=20, KV-cached, encoder once
+MFMA_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(cfg, weights, budget_s: float = 25.0):
+    """oracle/git_oracle.py (fp32, encoder once + exact KV cache, batch 1) timed on the host cores:
+    the CPU restatement of the same path, a bounded sample of the same workload."""
+    from oracle.git_oracle import GitOracle, make_frames
+    # a 1-GPU box gives this job a 16-core share of the host; more threads only oversubscribe it
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    orc = GitOracle(cfg, weights)
+    frames = make_frames(1, FRAMES, cfg.image_size, seed=1234)
+    with torch.no_grad():
+        t0 = time.time()
+        orc.greedy_decode(frames, TOKENS, stop="never")           # warm-up
+        warm = time.time() - t0
+        times = []
+        while len(times) < 8 and (sum(times) + warm) < budget_s:
+            t0 = time.time()
+            orc.greedy_decode(frames, TOKENS, stop="never")
+            times.append(time.time() - t0)
+    med = float(np.median(times))
+    return {"value": round(1.0 / med, 4), "unit": "captions/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} captions (1 clip x {FRAMES} frames x {TOKENS} tokens each, batch 1, fp32, "
+                      f"KV-cached oracle) after 1 warm-up; median {med * 1e3:.0f} ms/caption",
+            "p50_latency_ms": round(med * 1e3, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumented pass")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU); see module docstring")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    from gitcap.config import git_base
+    from gitcap.model import GitCaptioner
+    from gitcap.weights import synthetic_weights
+
+    cfg = git_base(FRAMES)
+    weights = synthetic_weights(cfg, seed=0)
+    model = GitCaptioner(cfg, weights, device=dev, max_batch=CLIPS_PER_GPU, max_frames=FRAMES,
+                         max_text_len=TOKENS, stop="never")
+    # rank r holds clips [r*16, (r+1)*16) of the global batch; inputs are resident in HBM
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    frames = torch.randn(CLIPS_PER_GPU, FRAMES, 3, cfg.image_size, cfg.image_size, generator=g).to(dev)
+    gathered = torch.empty((world * CLIPS_PER_GPU, TOKENS + 1), dtype=torch.int64, device=dev) if world > 1 else None
+
+    def step():
+        ids = model.greedy_decode(frames, max_len=TOKENS, stop="never")
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, ids)    # rank-major: output row i is global clip i
+            return gathered
+        return ids
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(args.steps):
+        out = step()
+        evs[i + 1].record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lat = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    p50 = lat[len(lat) // 2]
+    if world > 1:
+        t = torch.tensor([elapsed, p50], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, p50 = float(t[0]), float(t[1])
+    assert out.shape == (world * CLIPS_PER_GPU, TOKENS + 1)
+
+    # ---- per-kernel-class timing: HIP events recorded by the library on its launch stream ----
+    roofline, breakdown = None, None
+    if not args.no_profile:
+        model.profile(True)
+        nprof = min(args.steps, 5)
+        for _ in range(nprof):
+            model.greedy_decode(frames, max_len=TOKENS, stop="never")
+        torch.cuda.synchronize(dev)
+        prof = model.profile_read()
+        model.profile(False)
+        breakdown = {k: {"ms_per_step": round(v["ms"] / nprof, 4), "launches_per_step": v["launches"] // nprof}
+                     for k, v in prof.items()}
+        gm = prof["gemm"]
+        avg_ms = gm["ms"] / max(1, gm["launches"])
+        achieved = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": gm["launches"] // nprof, "avg_launch_ms": round(avg_ms, 4),
+                    "algorithmic_gflop_per_launch": round(gm["flops"] / max(1, gm["launches"]) / 1e9, 2)}
+        sk, at = prof["skinny"], prof["attn_text"]
+        if sk["ms"] + at["ms"] > 0:
+            roofline["decode_hbm"] = {"bound": "hbm", "achieved": round((sk["bytes"] + at["bytes"]) / ((sk["ms"] + at["ms"]) * 1e-3) / 1e9, 1),
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round((sk["bytes"] + at["bytes"]) / ((sk["ms"] + at["ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, weights)
+
+    if rank == 0:
+        captions = world * CLIPS_PER_GPU * args.steps
+        value = captions / elapsed
+        line = {
+            "metric": "captions/sec", "value": round(value, 2), "unit": "captions/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "p50_latency_ms": round(p50, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: batch=16 6-frame 224x224 clips per GPU, GIT-base "
+                                   "(ViT-B/16 + 6-layer decoder), 20-token greedy, EOS disabled",
+                       "clips_per_gpu": CLIPS_PER_GPU, "frames": FRAMES, "tokens": TOKENS, "global_batch": world * CLIPS_PER_GPU,
+                       "parallelism": f"dp{world}", "collective": "all_gather(int64[16,21]) per step" if world > 1 else "none"},
+            "caption_mfma_frac": round(value / world * GFLOP_PER_CAPTION / 1e3 / MFMA_PEAK_TFLOPS, 4),
+            "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,22 @@ int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, i
 /* Beam reorder of the text part of the KV cache (what src/models/model.py:623-634 sketches):
  * new row r takes the cached text K/V of old row src_rows[r]; image K/V are shared. */
 int gitcap_reorder_rows(gitcap_t* h, const int32_t* src_rows, int rows, int t_len, void* stream);
+/* Instrumentation used by bench.py (no reference counterpart: the reference has no profiler,
+ * SURVEY.md par. 5).  When enabled every launch of a kernel class is bracketed by two HIP events
+ * recorded on the launch stream; gitcap_profile_read waits for them, sums the elapsed times and
+ * the algorithmic flops/bytes of the bracketed launches, and resets the class. */
+enum {
+    GITCAP_PROF_GEMM = 0,       /* bf16 MFMA GEMM (patch-embed, qkv, proj, fc1, fc2, vproj) */
+    GITCAP_PROF_ATTN_FULL = 1,  /* flash attention over frames / image prefix */
+    GITCAP_PROF_SKINNY = 2,     /* text-row weight-streaming GEMMs (incl. vocabulary head) */
+    GITCAP_PROF_ATTN_TEXT = 3,  /* text-row attention over the KV cache */
+    GITCAP_PROF_ROWOPS = 4,     /* LayerNorm */
+    GITCAP_PROF_CLASSES = 5
+};
+int gitcap_profile_enable(gitcap_t* h, int enable);
+int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launches,
+                        double* flops_total, double* bytes_total);
+
 /* Introspection used by tests and bench.py */
 int gitcap_workspace_bytes(const gitcap_t* h, int64_t* bytes);
 int gitcap_abi_version(void);

@@ -16,7 +16,7 @@
 //
 // attn_text_kernel: text rows (prefill with T tokens or one decode step).  HBM-bound K/V
 //   streaming straight to VGPRs, 8 lanes per key row (16 B each), per-8-lane-group online softmax
-//   state so the inner loop has no cross-group traffic; groups/waves/splits are merged at the end.
+//   state so the inner loop has no cross-group traffic; groups and waves are merged at the end.
 #include "kernels.h"
 
 namespace {
@@ -193,19 +193,19 @@ __device__ __forceinline__ void merge(Part& a, float m2, float l2, const float* 
     a.m = M;
 }
 
-__global__ __launch_bounds__(256) void attn_text_kernel(TextAttnArgs a) {
-    __shared__ float wsm[4][8][10];
+// One 16-wave workgroup per (text row m, head).  Wave w takes the 32-key groups w, w+16, ... : the
+// partition (and therefore the summation order) depends only on the key count, never on the batch
+// size, so a clip decodes to bitwise the same logits alone or inside any batch.
+__global__ __launch_bounds__(1024) void attn_text_kernel(TextAttnArgs a) {
+    __shared__ float wsm[16][8][10];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = blockIdx.x, head = blockIdx.y, split = blockIdx.z;
+    const int m = blockIdx.x, head = blockIdx.y;
     const int r = m / a.T, j = m - r * a.T;
     const int clip = r / a.beams;
     const int D = a.D, ld = 3 * D;
     const int tq = a.t0 + j;
     const int Lk = a.S_img + tq + 1;
-    const int chunk = (Lk + a.nsplit - 1) / a.nsplit;
-    const int kbeg = split * chunk;
-    const int kend = min(Lk, kbeg + chunk);
     const int sub = lane & 7, kk = lane >> 3;
 
     const bf16_t* img = a.kv_img + (size_t)clip * a.S_img * ld + D + head * 64 + sub * 8;
@@ -222,14 +222,14 @@ __global__ __launch_bounds__(256) void attn_text_kernel(TextAttnArgs a) {
 #pragma unroll
     for (int d = 0; d < 8; ++d) st.o[d] = 0.f;
 
-    for (int g0 = kbeg + wid * 32; g0 < kend; g0 += 128) {
+    for (int g0 = wid * 32; g0 < Lk; g0 += 16 * 32) {
         bf16x8 kf[4], vf[4];
         bool valid[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             int key = g0 + u * 8 + kk;
-            valid[u] = key < kend;
-            key = valid[u] ? key : kbeg;                        // kbeg < kend is guaranteed inside the loop
+            valid[u] = key < Lk;
+            key = valid[u] ? key : 0;
             const bf16_t* kp = key < a.S_img ? img + (size_t)key * ld : txt + (size_t)(key - a.S_img) * ld;
             kf[u] = *(const bf16x8*)kp;
             vf[u] = *(const bf16x8*)(kp + D);
@@ -283,38 +283,13 @@ __global__ __launch_bounds__(256) void attn_text_kernel(TextAttnArgs a) {
         t.m = wsm[0][tid][0]; t.l = wsm[0][tid][1];
 #pragma unroll
         for (int d = 0; d < 8; ++d) t.o[d] = wsm[0][tid][2 + d];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) merge(t, wsm[w][tid][0], wsm[w][tid][1], &wsm[w][tid][2]);
-        if (a.nsplit == 1) {
-            const float inv = 1.0f / t.l;
-            uint4 v;
-            v.x = pack_bf2(t.o[0] * inv, t.o[1] * inv); v.y = pack_bf2(t.o[2] * inv, t.o[3] * inv);
-            v.z = pack_bf2(t.o[4] * inv, t.o[5] * inv); v.w = pack_bf2(t.o[6] * inv, t.o[7] * inv);
-            *(uint4*)(a.ctx + (size_t)m * D + head * 64 + tid * 8) = v;
-        } else {
-            float* pp = a.part + (((size_t)m * a.H + head) * a.nsplit + split) * 66;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) pp[tid * 8 + d] = t.o[d];
-            if (tid == 0) { pp[64] = t.m; pp[65] = t.l; }
-        }
+        for (int w = 1; w < 16; ++w) merge(t, wsm[w][tid][0], wsm[w][tid][1], &wsm[w][tid][2]);
+        const float inv = 1.0f / t.l;
+        uint4 v;
+        v.x = pack_bf2(t.o[0] * inv, t.o[1] * inv); v.y = pack_bf2(t.o[2] * inv, t.o[3] * inv);
+        v.z = pack_bf2(t.o[4] * inv, t.o[5] * inv); v.w = pack_bf2(t.o[6] * inv, t.o[7] * inv);
+        *(uint4*)(a.ctx + (size_t)m * D + head * 64 + tid * 8) = v;
     }
-}
-
-// merge split partials: one wave per (m, head); lane = d
-__global__ __launch_bounds__(64) void attn_text_combine(const float* __restrict__ part, bf16_t* __restrict__ ctx,
-                                                        int H, int D, int nsplit) {
-    const int m = blockIdx.x, head = blockIdx.y, d = threadIdx.x;
-    const float* pp = part + ((size_t)m * H + head) * nsplit * 66;
-    float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pp[s * 66 + 64]);
-    float l = 0.f, o = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float ms = pp[s * 66 + 64];
-        const float sc = (ms == -INFINITY) ? 0.f : fast_exp2(ms - M);
-        l += pp[s * 66 + 65] * sc;
-        o += pp[s * 66 + d] * sc;
-    }
-    ctx[(size_t)m * D + head * 64 + d] = f2bf(o / l);
 }
 
 }  // namespace
@@ -328,13 +303,7 @@ hipError_t launch_attn_full(const bf16_t* qkv, bf16_t* ctx, int G, int S, int H,
 
 hipError_t launch_attn_text(const TextAttnArgs& a, hipStream_t s) {
     const int M = a.rows * a.T;
-    if (M <= 0 || a.nsplit < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_text_kernel, dim3(M, a.H, a.nsplit), dim3(256), 0, s, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (a.nsplit > 1) {
-        hipLaunchKernelGGL(attn_text_combine, dim3(M, a.H), dim3(64), 0, s, a.part, a.ctx, a.H, a.D, a.nsplit);
-        e = hipGetLastError();
-    }
-    return e;
+    if (M <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_text_kernel, dim3(M, a.H), dim3(1024), 0, s, a);
+    return hipGetLastError();
 }

@@ -59,7 +59,8 @@ struct gitcap {
     float *x = nullptr, *tmp = nullptr, *visual = nullptr;
     bf16_t *hb = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr, *patches = nullptr, *kv_img = nullptr;
     // workspace (text rows)
-    float *xs = nullptr, *ts = nullptr, *logits = nullptr, *part = nullptr;
+    float *xs = nullptr, *slabs = nullptr, *amax_val = nullptr;
+    int* amax_idx = nullptr;
     bf16_t *xsb = nullptr, *cs = nullptr, *fs = nullptr, *kv_txt = nullptr, *kv_txt2 = nullptr;
     int32_t* sep_cnt = nullptr;
 
@@ -75,6 +76,13 @@ struct gitcap {
     // state
     int cur_B = 0, cur_S = 0;
     bool have_image = false;
+    double prof_rows = 0;   // valid rows of the GEMMs being launched (set by the callers of gemm())
+
+    // instrumentation (bench.py): HIP-event brackets per kernel class, on the launch stream
+    bool prof_on = false;
+    struct ProfRec { hipEvent_t a, b; double flops, bytes; };
+    struct ProfClass { std::vector<ProfRec> recs; size_t used = 0; };
+    ProfClass prof[GITCAP_PROF_CLASSES];
 };
 
 namespace {
@@ -92,6 +100,23 @@ int fail(const gitcap* h, int code, const std::string& msg) {
         if (e_ != hipSuccess)                                                                         \
             return fail(h, GITCAP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
     } while (0)
+
+struct ProfScope {
+    gitcap* h; hipStream_t s; gitcap::ProfRec* r = nullptr;
+    ProfScope(gitcap* h_, int cls, hipStream_t s_, double flops, double bytes) : h(h_), s(s_) {
+        if (!h->prof_on) return;
+        gitcap::ProfClass& pc = h->prof[cls];
+        if (pc.used == pc.recs.size()) {
+            gitcap::ProfRec n{};
+            if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
+            pc.recs.push_back(n);
+        }
+        r = &pc.recs[pc.used++];
+        r->flops = flops; r->bytes = bytes;
+        (void)hipEventRecord(r->a, s);
+    }
+    ~ProfScope() { if (r) (void)hipEventRecord(r->b, s); }
+};
 
 // canonical names -> (shape, is_gemm_weight); mirrors gitcap/weights.py:canonical_shapes
 void expected_shapes(const gitcap_config& c, std::vector<std::pair<std::string, std::vector<int64_t>>>& out) {
@@ -146,6 +171,7 @@ int ws_alloc(gitcap* h, T** p, size_t count) {
 
 int ln(gitcap* h, hipStream_t s, const float* x, int ldx, const float* g, const float* b, float eps, int rows, int D,
        float* of, int ldf, bf16_t* ob, int ldb, const float* addv = nullptr, int add_div = 1, int add_mod = 1) {
+    ProfScope ps(h, GITCAP_PROF_ROWOPS, s, 0.0, (double)rows * D * (4.0 + (of ? 4.0 : 0.0) + (ob ? 2.0 : 0.0)));
     LnArgs a{x, ldx, g, b, eps, rows, D, of, ldf, ob, ldb, addv, add_div, add_mod};
     HIP_OK(h, launch_layernorm(a, s));
     return 0;
@@ -153,6 +179,8 @@ int ln(gitcap* h, hipStream_t s, const float* x, int ldx, const float* g, const 
 
 int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const bf16_t* W, const float* bias, int M, int N,
          int K, void* out, int ldo, const float* resid = nullptr, int ldr = 0) {
+    // algorithmic work: the VALID rows (h->prof_rows), not the 128-padded M that is launched
+    ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * h->prof_rows * N * K, 0.0);
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
     a.resid = resid; a.ldr = ldr;
@@ -161,10 +189,24 @@ int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const bf16
 }
 
 int skinny(gitcap* h, hipStream_t s, int epi, const bf16_t* X, int ldx, const bf16_t* W, const float* bias, int M,
-           int N, int K, void* out, int ldo, int T = 1, int row_stride = 1, int row_off = 0,
-           const float* resid = nullptr, int ldr = 0) {
-    SkinnyArgs a{X, ldx, W, bias, M, N, K, out, ldo, T, row_stride, row_off, resid, ldr};
+           int N, int K, void* out, int ldo, int T = 1, int row_stride = 1, int row_off = 0) {
+    ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * M * N * K, 2.0 * N * K);
+    SkinnyArgs a{X, ldx, W, bias, M, N, K, out, ldo, T, row_stride, row_off, nullptr, nullptr};
     HIP_OK(h, launch_skinny(a, epi, s));
+    return 0;
+}
+
+int skinny_splitk(gitcap* h, hipStream_t s, const bf16_t* X, int ldx, const bf16_t* W, int M, int N, int K, float* slabs) {
+    ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * M * N * K, 2.0 * N * K);
+    SkinnyArgs a{X, ldx, W, nullptr, M, N, K, slabs, N, 1, 1, 0, nullptr, nullptr};
+    HIP_OK(h, launch_skinny_splitk(a, s));
+    return 0;
+}
+
+int ln_reduce(gitcap* h, hipStream_t s, const float* slabs, int nslab, const float* bias, const float* resid,
+              const float* g, const float* b, float eps, int M, int D, float* xf, bf16_t* xb) {
+    ProfScope ps(h, GITCAP_PROF_ROWOPS, s, 0.0, (double)M * D * (4.0 * nslab + 4.0 + 6.0));
+    HIP_OK(h, launch_ln_reduce(slabs, nslab, bias, resid, g, b, eps, M, D, xf, xb, s));
     return 0;
 }
 
@@ -173,6 +215,7 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
     const gitcap_config& c = h->c;
     const int D = h->D, Dv = h->Dv, rows = B * S, Mp = pad_to(rows, 128);
     int rc;
+    h->prof_rows = rows;
     // 'linearLn' projection: Linear(Dv -> D) + LayerNorm
     if ((rc = gemm(h, s, EPI_BIAS_F32, h->hb, Dv, h->vproj_w, h->vproj_b, Mp, D, Dv, h->tmp, D))) return rc;
     if ((rc = ln(h, s, h->tmp, D, h->vproj_lnw, h->vproj_lnb, c.proj_ln_eps, rows, D, h->x, D, h->hb, D))) return rc;
@@ -182,7 +225,10 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
         bf16_t* kv = h->kv_img + (size_t)l * kv_layer;
         if (l + 1 < c.dec_layers) {
             if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, D, L.qkvw, L.qkvb, Mp, 3 * D, D, kv, 3 * D))) return rc;
-            HIP_OK(h, launch_attn_full(kv, h->ctx, B, S, c.dec_heads, s));
+            {
+                ProfScope ps(h, GITCAP_PROF_ATTN_FULL, s, 4.0 * B * c.dec_heads * (double)S * S * 64, 0.0);
+                HIP_OK(h, launch_attn_full(kv, h->ctx, B, S, c.dec_heads, s));
+            }
             if ((rc = gemm(h, s, EPI_BIAS_RESID_F32, h->ctx, D, L.aow, L.aob, Mp, D, D, h->tmp, D, h->x, D))) return rc;
             if ((rc = ln(h, s, h->tmp, D, L.ln1w, L.ln1b, c.dec_ln_eps, rows, D, h->x, D, h->hb, D))) return rc;
             if ((rc = gemm(h, s, EPI_BIAS_GELU_BF16, h->hb, D, L.fc1w, L.fc1b, Mp, c.dec_ffn, D, h->ffn, c.dec_ffn))) return rc;
@@ -211,37 +257,46 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     int rc;
     HIP_OK(h, launch_embed_text(ids, ld_ids, rows, T, t0, h->word, h->tpos, h->txt_lnw, h->txt_lnb, c.dec_ln_eps, D,
                                 c.vocab_size, h->xs, h->xsb, s));
-    int nsplit = (768 + M * H - 1) / (M * H);
-    nsplit = nsplit < 1 ? 1 : (nsplit > 8 ? 8 : nsplit);
     const size_t kvi_layer = (size_t)h->Mi * 3 * D, kvt_layer = (size_t)h->R * h->Tmax * 3 * D;
+    const int ks_d = skinny_ksplit(D), ks_f = skinny_ksplit(c.dec_ffn);
     for (int l = 0; l < c.dec_layers; ++l) {
         const DecLayer& L = h->dec[l];
         bf16_t* kvt = h->kv_txt + (size_t)l * kvt_layer;
         if ((rc = skinny(h, s, SK_BIAS_BF16, h->xsb, D, L.qkvw, L.qkvb, M, 3 * D, D, kvt, 3 * D, T, h->Tmax, t0))) return rc;
-        TextAttnArgs ta{h->kv_img + (size_t)l * kvi_layer, kvt, h->cs, h->part, rows, beams, t0, T, h->Tmax, h->cur_S, H, D, nsplit};
-        HIP_OK(h, launch_attn_text(ta, s));
-        if ((rc = skinny(h, s, SK_BIAS_RESID_F32, h->cs, D, L.aow, L.aob, M, D, D, h->ts, D, 1, 1, 0, h->xs, D))) return rc;
-        if ((rc = ln(h, s, h->ts, D, L.ln1w, L.ln1b, c.dec_ln_eps, M, D, h->xs, D, h->xsb, D))) return rc;
+        {
+            double kvb = 0;
+            for (int j = 0; j < T; ++j) kvb += (double)rows * (h->cur_S + t0 + j + 1) * 2 * D * 2;
+            ProfScope ps(h, GITCAP_PROF_ATTN_TEXT, s, 0.0, kvb);
+            TextAttnArgs ta{h->kv_img + (size_t)l * kvi_layer, kvt, h->cs, rows, beams, t0, T, h->Tmax, h->cur_S, H, D};
+            HIP_OK(h, launch_attn_text(ta, s));
+        }
+        // attention output dense: split-K partial slabs, then sum + bias + residual + LayerNorm in one row kernel
+        if ((rc = skinny_splitk(h, s, h->cs, D, L.aow, M, D, D, h->slabs))) return rc;
+        if ((rc = ln_reduce(h, s, h->slabs, ks_d, L.aob, h->xs, L.ln1w, L.ln1b, c.dec_ln_eps, M, D, h->xs, h->xsb))) return rc;
         if ((rc = skinny(h, s, SK_BIAS_GELU_BF16, h->xsb, D, L.fc1w, L.fc1b, M, c.dec_ffn, D, h->fs, c.dec_ffn))) return rc;
-        if ((rc = skinny(h, s, SK_BIAS_RESID_F32, h->fs, c.dec_ffn, L.fc2w, L.fc2b, M, D, c.dec_ffn, h->ts, D, 1, 1, 0, h->xs, D))) return rc;
-        if ((rc = ln(h, s, h->ts, D, L.ln2w, L.ln2b, c.dec_ln_eps, M, D, h->xs, D, h->xsb, D))) return rc;
+        if ((rc = skinny_splitk(h, s, h->fs, c.dec_ffn, L.fc2w, M, D, c.dec_ffn, h->slabs))) return rc;
+        if ((rc = ln_reduce(h, s, h->slabs, ks_f, L.fc2b, h->xs, L.ln2w, L.ln2b, c.dec_ln_eps, M, D, h->xs, h->xsb))) return rc;
     }
     if (!logits_out && !argmax_out) return 0;
-    const int V = c.vocab_size;
-    const float* last_logits;
-    int last_ld;
+    // vocabulary head (+ arg-max partials per 16-column tile, reduced by argmax_final)
+    const int V = c.vocab_size, ntiles = (V + 15) / 16;
+    SkinnyArgs ha{};
+    ha.W = h->head_w; ha.bias = h->head_b; ha.N = V; ha.K = D; ha.ldo = V; ha.T = 1; ha.row_stride = 1; ha.row_off = 0;
+    int am_stride = 1, am_off = 0;
     if (all_positions && logits_out) {
-        if ((rc = skinny(h, s, SK_BIAS_F32, h->xsb, D, h->head_w, h->head_b, M, V, D, logits_out, V))) return rc;
-        last_logits = logits_out + (size_t)(T - 1) * V;
-        last_ld = T * V;
+        ha.X = h->xsb; ha.ldx = D; ha.M = M; ha.out = logits_out;
+        am_stride = T; am_off = T - 1;
     } else {
-        float* dst = logits_out ? logits_out : h->logits;
-        if ((rc = skinny(h, s, SK_BIAS_F32, h->xsb + (size_t)(T - 1) * D, T * D, h->head_w, h->head_b, rows, V, D, dst, V))) return rc;
-        last_logits = dst;
-        last_ld = V;
+        ha.X = h->xsb + (size_t)(T - 1) * D; ha.ldx = T * D; ha.M = rows; ha.out = logits_out;
+    }
+    if (argmax_out) { ha.amax_val = h->amax_val; ha.amax_idx = h->amax_idx; }
+    {
+        ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * ha.M * V * D, 2.0 * V * D);
+        HIP_OK(h, launch_skinny(ha, SK_BIAS_F32, s));
     }
     if (argmax_out)
-        HIP_OK(h, launch_argmax(last_logits, last_ld, rows, V, argmax_out, ld_argmax, sep_cnt, step, c.sep_token_id, s));
+        HIP_OK(h, launch_argmax_final(h->amax_val, h->amax_idx, ntiles, rows, am_stride, am_off, argmax_out, ld_argmax,
+                                      sep_cnt, step, c.sep_token_id, s));
     return 0;
 }
 
@@ -306,12 +361,12 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     rc = rc ? rc : ws_alloc(h, &h->patches, (size_t)h->Pp * h->Kp);
     rc = rc ? rc : ws_alloc(h, &h->kv_img, (size_t)c.dec_layers * Mi * 3 * h->D);
     rc = rc ? rc : ws_alloc(h, &h->xs, Mt * h->D);
-    rc = rc ? rc : ws_alloc(h, &h->ts, Mt * h->D);
+    rc = rc ? rc : ws_alloc(h, &h->slabs, (size_t)16 * Mt * h->D);
     rc = rc ? rc : ws_alloc(h, &h->xsb, Mt * h->D);
     rc = rc ? rc : ws_alloc(h, &h->cs, Mt * h->D);
     rc = rc ? rc : ws_alloc(h, &h->fs, Mt * c.dec_ffn);
-    rc = rc ? rc : ws_alloc(h, &h->logits, (size_t)h->R * h->V);
-    rc = rc ? rc : ws_alloc(h, &h->part, Mt * c.dec_heads * 8 * 66);
+    rc = rc ? rc : ws_alloc(h, &h->amax_val, Mt * (size_t)((h->V + 15) / 16));
+    rc = rc ? rc : ws_alloc(h, &h->amax_idx, Mt * (size_t)((h->V + 15) / 16));
     rc = rc ? rc : ws_alloc(h, &h->kv_txt, (size_t)c.dec_layers * h->R * h->Tmax * 3 * h->D);
     rc = rc ? rc : ws_alloc(h, &h->kv_txt2, (size_t)c.dec_layers * h->R * h->Tmax * 3 * h->D);
     rc = rc ? rc : ws_alloc(h, &h->sep_cnt, (size_t)h->Tmax + 1);
@@ -334,6 +389,8 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
 
 void gitcap_destroy(gitcap_t* h) {
     if (!h) return;
+    for (auto& pc : h->prof)
+        for (auto& r : pc.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto& kv : h->w)
         if (kv.second.p) (void)hipFree(kv.second.p);
@@ -416,19 +473,24 @@ int gitcap_encode(gitcap_t* h, const float* frames, int B, int F, float* visual_
     // patchify (conv k = stride = p, no bias) + CLS + position embedding, then ln_pre
     HIP_OK(h, launch_im2col(frames, h->patches, nf, c.image_size, c.patch_size, h->Kp, s));
     {
+        ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * P * Dv * (3.0 * c.patch_size * c.patch_size), 0.0);
         GemmArgs a{};
         a.A = h->patches; a.lda = h->Kp; a.W = h->patch_w; a.bias = nullptr; a.M = Pp; a.N = Dv; a.K = h->Kp;
         a.out = h->x; a.ldo = Dv; a.pos = h->pos; a.tokens_per_frame = N; a.patches_per_frame = h->G * h->G; a.valid_rows = P;
         HIP_OK(h, launch_gemm(a, EPI_PATCH_F32, s));
     }
     HIP_OK(h, launch_cls_rows(h->x, h->cls, h->pos, nf, N, Dv, s));
+    h->prof_rows = rows;
     if ((rc = ln(h, s, h->x, Dv, h->ln_pre_w, h->ln_pre_b, c.enc_ln_eps, rows, Dv, h->x, Dv, nullptr, 0))) return rc;
 
     for (int i = 0; i < c.enc_layers; ++i) {
         const EncLayer& L = h->enc[i];
         if ((rc = ln(h, s, h->x, Dv, L.ln1w, L.ln1b, c.enc_ln_eps, rows, Dv, nullptr, 0, h->hb, Dv))) return rc;
         if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, Dv, L.qkvw, L.qkvb, Mp, 3 * Dv, Dv, h->qkv, 3 * Dv))) return rc;
-        HIP_OK(h, launch_attn_full(h->qkv, h->ctx, nf, N, c.enc_heads, s));
+        {
+            ProfScope ps(h, GITCAP_PROF_ATTN_FULL, s, 4.0 * nf * c.enc_heads * (double)N * N * 64, 0.0);
+            HIP_OK(h, launch_attn_full(h->qkv, h->ctx, nf, N, c.enc_heads, s));
+        }
         if ((rc = gemm(h, s, EPI_BIAS_RESID_F32, h->ctx, Dv, L.projw, L.projb, Mp, Dv, Dv, h->x, Dv, h->x, Dv))) return rc;
         if ((rc = ln(h, s, h->x, Dv, L.ln2w, L.ln2b, c.enc_ln_eps, rows, Dv, nullptr, 0, h->hb, Dv))) return rc;
         if ((rc = gemm(h, s, EPI_BIAS_QGELU_BF16, h->hb, Dv, L.fc1w, L.fc1b, Mp, c.enc_ffn, Dv, h->ffn, c.enc_ffn))) return rc;
@@ -493,6 +555,31 @@ int gitcap_reorder_rows(gitcap_t* h, const int32_t* src_rows, int rows, int t_le
     for (int l = 0; l < h->c.dec_layers; ++l)
         HIP_OK(h, launch_gather_txt_rows(h->kv_txt + l * layer, h->kv_txt2 + l * layer, src_rows, rows, t_len, h->Tmax, 3 * h->D, s));
     std::swap(h->kv_txt, h->kv_txt2);
+    return 0;
+}
+
+int gitcap_profile_enable(gitcap_t* h, int enable) {
+    if (!h) return GITCAP_ERR_ARG;
+    h->prof_on = enable != 0;
+    return 0;
+}
+
+int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launches, double* flops_total,
+                        double* bytes_total) {
+    if (!h || cls < 0 || cls >= GITCAP_PROF_CLASSES) return fail(h, GITCAP_ERR_ARG, "profile_read: bad class");
+    gitcap::ProfClass& pc = h->prof[cls];
+    double ms = 0, fl = 0, by = 0;
+    for (size_t i = 0; i < pc.used; ++i) {
+        HIP_OK(h, hipEventSynchronize(pc.recs[i].b));
+        float t = 0;
+        HIP_OK(h, hipEventElapsedTime(&t, pc.recs[i].a, pc.recs[i].b));
+        ms += t; fl += pc.recs[i].flops; by += pc.recs[i].bytes;
+    }
+    if (ms_total) *ms_total = ms;
+    if (launches) *launches = (int64_t)pc.used;
+    if (flops_total) *flops_total = fl;
+    if (bytes_total) *bytes_total = by;
+    pc.used = 0;
     return 0;
 }
 

@@ -23,20 +23,27 @@ struct GemmArgs {
 };
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
 
-// ---- skinny GEMM (M <= a few 16-row tiles): weight-streaming, split-K over the 4 waves -----
-enum SkinnyEpi {
-    SK_BIAS_BF16 = 0, SK_BIAS_GELU_BF16 = 1, SK_BIAS_RESID_F32 = 2, SK_BIAS_F32 = 3
-};
+// ---- skinny GEMMs (text rows; M = a few 16-row tiles): weight streaming, one wave per tile ----
+enum SkinnyEpi { SK_BIAS_BF16 = 0, SK_BIAS_GELU_BF16 = 1, SK_BIAS_F32 = 3 };
 struct SkinnyArgs {
-    const bf16_t* X; int ldx;     // [Mpad16][ldx] bf16 activations (row m at X + m*ldx)
+    const bf16_t* X; int ldx;     // bf16 activations, row m at X + m*ldx
     const bf16_t* W;              // [Npad16][K]
-    const float* bias;            // [N]
-    int M, N, K;                  // M valid rows, N valid cols (weights padded to 16 rows), K % 128 == 0
-    void* out;                    // row m -> out + orow(m)*ldo, orow(m) = (m / T)*row_stride + row_off + m % T
-    int ldo, T, row_stride, row_off;
-    const float* resid; int ldr;  // f32 [M][ldr]
+    const float* bias;            // [N] (full kernel only)
+    int M, N, K;                  // M valid rows, N valid cols (weight rows padded to 16)
+    void* out;                    // full: row m -> out + orow(m)*ldo, orow(m) = (m / T)*row_stride + row_off + m % T
+    int ldo, T, row_stride, row_off;   // splitk: out = fp32 slabs [ksplit][M][ldo]
+    float* amax_val; int* amax_idx;    // SK_BIAS_F32 only (nullable): per-tile arg-max partials [M][ntiles]
 };
 hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s);
+int skinny_ksplit(int K);                                    // number of K slabs launch_skinny_splitk writes
+hipError_t launch_skinny_splitk(const SkinnyArgs& a, hipStream_t s);
+// x = LayerNorm(sum_s slab[s][m][:] + bias + resid[m][:]) -> xf (fp32) and xb (bf16); one wave per row
+hipError_t launch_ln_reduce(const float* slabs, int nslab, const float* bias, const float* resid,
+                            const float* gamma, const float* beta, float eps, int M, int D,
+                            float* xf, bf16_t* xb, hipStream_t s);
+// out[r*ld_out] = index of the max over the per-tile partials of row r*row_stride + row_off
+hipError_t launch_argmax_final(const float* amax_val, const int* amax_idx, int ntiles, int rows, int row_stride,
+                               int row_off, int64_t* out, int ld_out, int32_t* sep_cnt, int step, int sep_id, hipStream_t s);
 
 // ---- attention ---------------------------------------------------------------------------
 // Full (unmasked) self-attention over groups of S rows: qkv [G*S][3*W] bf16 (q | k | v, head h
@@ -49,8 +56,7 @@ struct TextAttnArgs {
     const bf16_t* kv_img;   // [B*S_img][3D] this layer
     const bf16_t* kv_txt;   // [R][Tmax][3D] this layer (q at cols 0..D)
     bf16_t* ctx;            // [R*T][D]
-    float* part;            // [R*T][H][nsplit][66] scratch
-    int rows, beams, t0, T, Tmax, S_img, H, D, nsplit;
+    int rows, beams, t0, T, Tmax, S_img, H, D;
 };
 hipError_t launch_attn_text(const TextAttnArgs& a, hipStream_t s);
 

@@ -162,6 +162,104 @@ __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restri
     }
 }
 
+// ---- split-K reduce + bias + residual + LayerNorm (text rows): one wave per row ----------------
+template <int NV>
+__global__ __launch_bounds__(64) void ln_reduce_kernel(const float* __restrict__ slabs, int nslab,
+                                                       const float* __restrict__ bias, const float* __restrict__ resid,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps, int M, int D, float* __restrict__ xf,
+                                                       bf16_t* __restrict__ xb) {
+    const int lane = threadIdx.x, m = blockIdx.x;
+    f32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // 8 slabs x NV vectors are requested before the first add (no serial latency chain); the
+    // summation order is fixed, so the result does not depend on launch geometry or timing
+    for (int k0 = 0; k0 < nslab; k0 += 8) {
+        f32x4 p[8][NV];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = i * 256 + lane * 4;
+                p[k][i] = (k0 + k < nslab && c < D) ? *(const f32x4*)(slabs + ((size_t)(k0 + k) * M + m) * D + c)
+                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            v[i] += ((p[0][i] + p[1][i]) + (p[2][i] + p[3][i])) + ((p[4][i] + p[5][i]) + (p[6][i] + p[7][i]));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+            v[i] += *(const f32x4*)(bias + c) + *(const f32x4*)(resid + (size_t)m * D + c);
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+            const f32x4 g = *(const f32x4*)(gamma + c);
+            const f32x4 b = *(const f32x4*)(beta + c);
+            f32x4 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            *(f32x4*)(xf + (size_t)m * D + c) = y;
+            uint2 o;
+            o.x = pack_bf2(y[0], y[1]);
+            o.y = pack_bf2(y[2], y[3]);
+            *(uint2*)(xb + (size_t)m * D + c) = o;
+        }
+    }
+}
+
+// ---- final arg-max over the per-tile partials written by the vocabulary-head kernel ------------
+__global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restrict__ val, const int* __restrict__ idx,
+                                                           int ntiles, int row_stride, int row_off,
+                                                           int64_t* __restrict__ out, int ld_out,
+                                                           int32_t* __restrict__ sep_cnt, int step, int sep_id) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const size_t base = (size_t)(r * row_stride + row_off) * ntiles;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < ntiles; i += 256) {
+        const float v = val[base + i];
+        const int j = idx[base + i];
+        if (v > best || (v == best && j < bi)) { best = v; bi = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(best, o);
+        const int i2 = __shfl_xor(bi, o);
+        if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+    }
+    if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        if (bi == 0x7fffffff) bi = 0;
+        out[(size_t)r * ld_out] = bi;
+        if (sep_cnt && bi == sep_id) atomicAdd(&sep_cnt[step], 1);
+    }
+}
+
 // ---- argmax: one block per row; lowest index wins ties (torch.argmax on CPU) -------------------
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int ld, int V,
                                                      int64_t* __restrict__ out, int ld_out,
@@ -230,6 +328,24 @@ hipError_t launch_layernorm(const LnArgs& a, hipStream_t s) {
         case 3: hipLaunchKernelGGL(layernorm_kernel<3>, dim3(grid), dim3(256), 0, s, a); break;
         default: hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, s, a); break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_ln_reduce(const float* slabs, int nslab, const float* bias, const float* resid, const float* gamma,
+                            const float* beta, float eps, int M, int D, float* xf, bf16_t* xb, hipStream_t s) {
+    if (M <= 0 || D % 4 || D > 1024 || nslab < 1) return hipErrorInvalidValue;
+    const int nv = (D + 255) / 256;
+    if (nv == 1) hipLaunchKernelGGL(ln_reduce_kernel<1>, dim3(M), dim3(64), 0, s, slabs, nslab, bias, resid, gamma, beta, eps, M, D, xf, xb);
+    else if (nv == 2) hipLaunchKernelGGL(ln_reduce_kernel<2>, dim3(M), dim3(64), 0, s, slabs, nslab, bias, resid, gamma, beta, eps, M, D, xf, xb);
+    else if (nv == 3) hipLaunchKernelGGL(ln_reduce_kernel<3>, dim3(M), dim3(64), 0, s, slabs, nslab, bias, resid, gamma, beta, eps, M, D, xf, xb);
+    else hipLaunchKernelGGL(ln_reduce_kernel<4>, dim3(M), dim3(64), 0, s, slabs, nslab, bias, resid, gamma, beta, eps, M, D, xf, xb);
+    return hipGetLastError();
+}
+
+hipError_t launch_argmax_final(const float* amax_val, const int* amax_idx, int ntiles, int rows, int row_stride, int row_off,
+                               int64_t* out, int ld_out, int32_t* sep_cnt, int step, int sep_id, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(rows), dim3(256), 0, s, amax_val, amax_idx, ntiles, row_stride, row_off,
+                       out, ld_out, sep_cnt, step, sep_id);
     return hipGetLastError();
 }
 

@@ -1,99 +1,171 @@
-// Skinny GEMM for the text path (M = rows*T, a handful of 16-row tiles): out[m][n] = X[m][:] . W[n][:].
+// Skinny GEMMs for the text path (M = rows*T is a handful of 16-row tiles):
+//     out[m][n] = X[m][:] . W[n][:]
+// HBM/latency bound weight streaming, not MFMA bound.  Every weight element is read exactly once,
+// straight from HBM into VGPRs (no LDS round trip: a weight tile is not shared between waves;
+// cdna_hip_programming.md "GEMV / M <= 16 decode weights").  The 16x16x32 bf16 MFMA is used because
+// 16 activation rows fit its N dimension exactly, so the dot products cost no VALU.
 //
-// This is HBM/latency bound weight streaming, not MFMA bound: each weight element is read once
-// from HBM straight into VGPRs (no LDS round trip: the weight tile is not shared between waves,
-// cdna_hip_programming.md "GEMV / M <= 16 decode weights").  The MFMA (16x16x32 bf16) is used only
-// because 16 activation rows fit its N dimension exactly, so the dot products cost no VALU.
+// One wave (= one 64-thread block, to spread over as many CUs as possible) owns one 16-row weight
+// tile; all of its weight fragments are requested back-to-back before the first MFMA so that a
+// whole matrix is in flight at once (a 768x768 matrix is 1.2 MB = 48 waves x 24 KiB).
 //
-// One block = one 16-row weight tile; its 4 waves split K in quarters and reduce through LDS.
+//   skinny_full  : whole K per wave, fused epilogue (bias [+GELU] -> bf16, or fp32 logits + a
+//                  per-tile arg-max partial for the vocabulary head).
+//   skinny_splitk: K split over blocks (more waves in flight for the K=3072 matrix and for the
+//                  N=768 ones that would otherwise use 48 waves); each wave writes its fp32
+//                  partial tile to a slab; ln_reduce_kernel (rowops.hip) sums the slabs in a fixed
+//                  order, adds bias + residual and applies LayerNorm.  No atomics: results are
+//                  bitwise reproducible and independent of the batch size.
 #include "kernels.h"
 
 namespace {
 
-constexpr int MT_MAX = 4;   // m-tiles (16 rows each) handled per pass
-
-template <int EPI>
-__global__ __launch_bounds__(256) void skinny_kernel(SkinnyArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[4][MT_MAX][64][4];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+template <int K32, int EPI>
+__global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
+    const int lane = threadIdx.x;
     const int frow = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * 16;
-    const int kq = a.K >> 2;
-    const int kbeg = wid * kq;
-    const bf16_t* wp = a.W + (size_t)(n0 + frow) * a.K + kbeg + fq * 8;
+    const bf16_t* wp = a.W + (size_t)(n0 + frow) * a.K + fq * 8;
+    bf16x8 wf[K32];
+#pragma unroll
+    for (int k = 0; k < K32; ++k) wf[k] = *(const bf16x8*)(wp + k * 32);
+
+    const int n = n0 + fq * 4;
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = (a.bias && n + r < a.N) ? a.bias[n + r] : 0.f;
+
     const int mtiles = (a.M + 15) >> 4;
-
-    for (int mt0 = 0; mt0 < mtiles; mt0 += MT_MAX) {
-        const bf16_t* xp[MT_MAX];
+    for (int mt = 0; mt < mtiles; ++mt) {
+        int m = mt * 16 + frow;
+        const bool mvalid = m < a.M;
+        m = mvalid ? m : a.M - 1;                               // clamp: padded rows are discarded
+        const bf16_t* xp = a.X + (size_t)m * a.ldx + fq * 8;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < MT_MAX; ++t) {
-            int m = (mt0 + t) * 16 + frow;
-            m = m < a.M ? m : a.M - 1;                         // clamp: padded rows are discarded
-            xp[t] = a.X + (size_t)m * a.ldx + kbeg + fq * 8;
+        for (int k = 0; k < K32; ++k) {
+            const bf16x8 xf = *(const bf16x8*)(xp + k * 32);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k], xf, acc, 0, 0, 0);
         }
-        f32x4 acc[MT_MAX];
+        // lane holds out[m][n .. n+3]
+        float y[4];
 #pragma unroll
-        for (int t = 0; t < MT_MAX; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int nact = min(MT_MAX, mtiles - mt0);            // wave-uniform
-
-        for (int k = 0; k < kq; k += 64) {
-            // K % 128 == 0  ->  kq % 32 == 0; handle two 32-steps per iteration when available
-            const bf16x8 w0 = *(const bf16x8*)(wp + k);
-            const bool two = (k + 32) < kq;
-            const bf16x8 w1 = two ? *(const bf16x8*)(wp + k + 32) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r = 0; r < 4; ++r) y[r] = acc[r] + bias[r];
+        if (EPI == SK_BIAS_GELU_BF16) {
 #pragma unroll
-            for (int t = 0; t < MT_MAX; ++t) {
-                if (t < nact) {
-                    const bf16x8 x0 = *(const bf16x8*)(xp[t] + k);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, x0, acc[t], 0, 0, 0);
-                    if (two) {
-                        const bf16x8 x1 = *(const bf16x8*)(xp[t] + k + 32);
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, x1, acc[t], 0, 0, 0);
-                    }
-                }
-            }
+            for (int r = 0; r < 4; ++r) y[r] = erf_gelu(y[r]);
         }
-#pragma unroll
-        for (int t = 0; t < MT_MAX; ++t) *(f32x4*)red[wid][t][lane] = acc[t];
-        __syncthreads();
-        // wave w finishes m-tile mt0 + w
-        if (wid < nact) {
-            f32x4 v = *(const f32x4*)red[0][wid][lane];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) v += *(const f32x4*)red[w][wid][lane];
-            const int m = (mt0 + wid) * 16 + frow;
-            const int n = n0 + fq * 4;
-            if (m < a.M) {
+        if (EPI == SK_BIAS_BF16 || EPI == SK_BIAS_GELU_BF16) {
+            if (mvalid) {
                 const int orow = (m / a.T) * a.row_stride + a.row_off + (m % a.T);
+                bf16_t* op = (bf16_t*)a.out + (size_t)orow * a.ldo + n;
+                if (n + 3 < a.N) {
+                    uint2 v;
+                    v.x = pack_bf2(y[0], y[1]);
+                    v.y = pack_bf2(y[2], y[3]);
+                    *(uint2*)op = v;
+                } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (n + r < a.N) {
-                        float y = v[r] + (a.bias ? a.bias[n + r] : 0.f);
-                        if (EPI == SK_BIAS_GELU_BF16) y = erf_gelu(y);
-                        if (EPI == SK_BIAS_RESID_F32) y += a.resid[(size_t)m * a.ldr + n + r];
-                        if (EPI == SK_BIAS_BF16 || EPI == SK_BIAS_GELU_BF16)
-                            ((bf16_t*)a.out)[(size_t)orow * a.ldo + n + r] = f2bf(y);
-                        else
-                            ((float*)a.out)[(size_t)orow * a.ldo + n + r] = y;
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < a.N) op[r] = f2bf(y[r]);
+                }
+            }
+        } else {  // SK_BIAS_F32: logits (+ arg-max partial of this 16-column tile)
+            if (mvalid && a.out) {
+                float* op = (float*)a.out + (size_t)m * a.ldo + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < a.N) op[r] = y[r];
+            }
+            if (a.amax_val) {
+                float best = -INFINITY;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < a.N && (y[r] > best)) { best = y[r]; bi = n + r; }   // ascending n: first max wins
+#pragma unroll
+                for (int off = 16; off < 64; off <<= 1) {
+                    const float v2 = __shfl_xor(best, off);
+                    const int i2 = __shfl_xor(bi, off);
+                    if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+                }
+                if (fq == 0 && mvalid) {
+                    a.amax_val[(size_t)m * gridDim.x + blockIdx.x] = best;
+                    a.amax_idx[(size_t)m * gridDim.x + blockIdx.x] = bi;
                 }
             }
         }
-        __syncthreads();
     }
+}
+
+// grid = (n_tiles, ksplit); slab[ks][m][n] fp32 partial sums (no bias)
+template <int K32>
+__global__ __launch_bounds__(64) void skinny_splitk_kernel(SkinnyArgs a) {
+    const int lane = threadIdx.x;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 16, ks = blockIdx.y;
+    const int kbeg = ks * K32 * 32;
+    const bf16_t* wp = a.W + (size_t)(n0 + frow) * a.K + kbeg + fq * 8;
+    bf16x8 wf[K32];
+#pragma unroll
+    for (int k = 0; k < K32; ++k) wf[k] = *(const bf16x8*)(wp + k * 32);
+    const int n = n0 + fq * 4;
+    float* slab = (float*)a.out + (size_t)ks * a.M * a.ldo;
+    const int mtiles = (a.M + 15) >> 4;
+    for (int mt = 0; mt < mtiles; ++mt) {
+        int m = mt * 16 + frow;
+        const bool mvalid = m < a.M;
+        m = mvalid ? m : a.M - 1;
+        const bf16_t* xp = a.X + (size_t)m * a.ldx + kbeg + fq * 8;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < K32; ++k) {
+            const bf16x8 xf = *(const bf16x8*)(xp + k * 32);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k], xf, acc, 0, 0, 0);
+        }
+        if (mvalid) *(f32x4*)(slab + (size_t)m * a.ldo + n) = acc;
+    }
+}
+
+template <int K32>
+hipError_t launch_full(const SkinnyArgs& a, int epi, hipStream_t s) {
+    const int grid = (a.N + 15) / 16;
+    switch (epi) {
+        case SK_BIAS_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16>), dim3(grid), dim3(64), 0, s, a); break;
+        case SK_BIAS_GELU_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_GELU_BF16>), dim3(grid), dim3(64), 0, s, a); break;
+        case SK_BIAS_F32: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_F32>), dim3(grid), dim3(64), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s) {
-    if (a.K % 128 || a.M <= 0 || a.T <= 0) return hipErrorInvalidValue;
-    const int grid = (a.N + 15) / 16;
-    switch (epi) {
-        case SK_BIAS_BF16: hipLaunchKernelGGL(skinny_kernel<SK_BIAS_BF16>, dim3(grid), dim3(256), 0, s, a); break;
-        case SK_BIAS_GELU_BF16: hipLaunchKernelGGL(skinny_kernel<SK_BIAS_GELU_BF16>, dim3(grid), dim3(256), 0, s, a); break;
-        case SK_BIAS_RESID_F32: hipLaunchKernelGGL(skinny_kernel<SK_BIAS_RESID_F32>, dim3(grid), dim3(256), 0, s, a); break;
-        case SK_BIAS_F32: hipLaunchKernelGGL(skinny_kernel<SK_BIAS_F32>, dim3(grid), dim3(256), 0, s, a); break;
+    if (a.K % 32 || a.M <= 0 || a.T <= 0) return hipErrorInvalidValue;
+    switch (a.K / 32) {
+        case 4: return launch_full<4>(a, epi, s);      // K = 128 (tiny test config)
+        case 8: return launch_full<8>(a, epi, s);      // K = 256
+        case 24: return launch_full<24>(a, epi, s);    // K = 768
+        case 32: return launch_full<32>(a, epi, s);    // K = 1024
+    }
+    return hipErrorInvalidValue;
+}
+
+int skinny_ksplit(int K) {
+    const int ks = K >= 2048 ? 16 : 4;
+    return (K % (ks * 32) == 0) ? ks : 0;
+}
+
+hipError_t launch_skinny_splitk(const SkinnyArgs& a, hipStream_t s) {
+    const int ks = skinny_ksplit(a.K);
+    if (!ks || a.M <= 0 || a.N % 16) return hipErrorInvalidValue;
+    dim3 grid(a.N / 16, ks);
+    switch (a.K / ks / 32) {
+        case 1: hipLaunchKernelGGL(skinny_splitk_kernel<1>, grid, dim3(64), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(skinny_splitk_kernel<2>, grid, dim3(64), 0, s, a); break;
+        case 6: hipLaunchKernelGGL(skinny_splitk_kernel<6>, grid, dim3(64), 0, s, a); break;
+        case 8: hipLaunchKernelGGL(skinny_splitk_kernel<8>, grid, dim3(64), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -25,6 +25,9 @@ SYMBOLS = {
                                     c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "gitcap_greedy": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gitcap_reorder_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "gitcap_profile_enable": (c_int, [c_void_p, c_int]),
+    "gitcap_profile_read": (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int64),
+                                    POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "gitcap_workspace_bytes": (c_int, [c_void_p, POINTER(c_int64)]),
 }
 

@@ -1,0 +1,55 @@
+"""Clip sharding across the GPUs of one node (one process per GPU) and the single collective of
+the path: a gather of the caption ids.
+
+The reference has no inference-time multi-GPU at all; it loops clips independently
+(/root/reference/src/models/model.py:765), which is what makes the path shard embarrassingly:
+rank r of R takes clips [r*B/R, (r+1)*B/R), holds a full weight replica, and nothing is exchanged
+during encode/decode.  Only the final ids (int64 [B/R, max_len+1], ~2.7 KB per rank at B/R = 16)
+are all-gathered, rank-major, so output row i is global clip i.  Backend "nccl" is RCCL on ROCm
+(xGMI between the GPUs of a node); "gloo" runs the same code on CPU tensors for tests.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_clips: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced partition: the first (n_clips % world) ranks take one extra clip."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    q, r = divmod(n_clips, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def gather_captions(ids: torch.Tensor, n_clips: int | None = None, group=None) -> torch.Tensor:
+    """All ranks receive the ids of all clips, rows in global clip order.  `ids` is this rank's
+    [b_local, L] int64 block; ragged shards (n_clips % world != 0) are padded for the collective
+    and trimmed afterwards."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return ids
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    L = ids.shape[1]
+    if n_clips is None:
+        n_clips = ids.shape[0] * world
+    sizes = [shard_range(n_clips, r, world) for r in range(world)]
+    bmax = max(hi - lo for lo, hi in sizes)
+    if ids.shape[0] != sizes[rank][1] - sizes[rank][0]:
+        raise ValueError("local block does not match shard_range")
+    pad = ids
+    if ids.shape[0] < bmax:
+        pad = torch.cat([ids, ids.new_zeros((bmax - ids.shape[0], L))], 0)
+    pad = pad.contiguous()
+    if dist.get_backend(group) == "gloo":
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
+        out = torch.cat(parts, 0)
+    else:
+        out = torch.empty((world * bmax, L), dtype=ids.dtype, device=ids.device)
+        dist.all_gather_into_tensor(out, pad, group=group)
+    if all(hi - lo == bmax for lo, hi in sizes):
+        return out
+    return torch.cat([out[r * bmax: r * bmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], 0)

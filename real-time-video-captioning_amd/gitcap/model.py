@@ -271,6 +271,21 @@ class GitCaptioner(nn.Module):
         with torch.cuda.device(self._dev):
             self._call("gitcap_reorder_rows", ctypes.c_void_p(idx.data_ptr()), idx.numel(), t_len, self._stream())
 
+    PROF_CLASSES = ("gemm", "attn_full", "skinny", "attn_text", "rowops")
+
+    def profile(self, enable: bool):
+        self._call("gitcap_profile_enable", int(bool(enable)))
+
+    def profile_read(self) -> dict:
+        """{class: {ms, launches, flops, bytes}} summed over the bracketed launches since the last read."""
+        out = {}
+        for i, name in enumerate(self.PROF_CLASSES):
+            ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            n = ctypes.c_int64()
+            self._call("gitcap_profile_read", i, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
+            out[name] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+        return out
+
     def workspace_bytes(self) -> int:
         n = ctypes.c_int64()
         self._lib.gitcap_workspace_bytes(self._handle, ctypes.byref(n))

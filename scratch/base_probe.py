@@ -1,0 +1,31 @@
+# scratch: base-config parity vs HF goldens + first timing
+import sys, time, numpy as np, torch
+sys.path.insert(0, 'real-time-video-captioning_amd'); sys.path.insert(0, '.')
+from gitcap.config import git_base
+from gitcap.weights import synthetic_weights
+from gitcap.model import GitCaptioner
+from oracle.git_oracle import GitOracle, make_frames
+for F, name in ((0, 'hf_base_F1.npz'), (6, 'hf_base_F6.npz')):
+    cfg = git_base(F); w = synthetic_weights(cfg, 0)
+    g = np.load('tests/golden/' + name)
+    fr = make_frames(2, max(1, F), cfg.image_size, 1234)
+    t0 = time.time(); m = GitCaptioner(cfg, w, max_batch=16, max_text_len=24); print('create+upload %.1fs ws=%.2f GB' % (time.time()-t0, m.workspace_bytes()/1e9))
+    out = m.greedy_decode(fr, max_len=20, stop='never').cpu().numpy()
+    print('F', F, 'match HF golden ids:', (out == g['greedy_ids']).mean(), out[0][:8], g['greedy_ids'][0][:8])
+    _, vis = m.forward_image_enc(fr)
+    vs = vis.cpu()[:, ::97, :32].numpy()
+    print('   visual slice max diff vs HF fp32', np.abs(vs - g['visual_slice']).max(), 'scale', np.abs(g['visual_slice']).max())
+    # teacher-forced logits on golden ids vs golden top values
+    ids = torch.from_numpy(g['greedy_ids'][:, :20])
+    lg = m.forward_decoder(ids, vis).cpu()
+    top_i = torch.from_numpy(g['greedy_top_ids']); top_v = torch.from_numpy(g['greedy_top_vals'])
+    dv = torch.gather(lg, 2, top_i) - top_v
+    print('   teacher-forced top8 logit diff vs HF fp32: max %.4f  mean %.4f ; logit std %.3f ; top1-top2 margin min %.4f' % (dv.abs().max(), dv.abs().mean(), lg.std(), (top_v[...,0]-top_v[...,1]).min()))
+    if F == 6:
+        fr16 = make_frames(16, 6, cfg.image_size, 99).cuda()
+        for it in range(3):
+            torch.cuda.synchronize(); t0 = time.time()
+            o = m.greedy_decode(fr16, max_len=20, stop='never'); torch.cuda.synchronize()
+            dt = time.time() - t0
+            print('   B=16 F=6 T=20: %.1f ms -> %.1f captions/s' % (dt*1e3, 16/dt))
+    del m

@@ -1,0 +1,84 @@
+"""Pins the CPU oracle (oracle/git_oracle.py) to the fixtures generated from the independent
+`transformers` implementation of GIT (oracle/gen_golden_hf.py).  The reference itself holds no
+golden vectors for this path (SURVEY.md par. 8c): these are the pins."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gitcap.config import git_base, git_tiny
+from gitcap.weights import synthetic_weights
+from oracle.git_oracle import GitOracle, make_frames
+
+
+@pytest.mark.parametrize("F", [2, 0])
+def test_tiny_oracle_matches_hf(golden_dir, F):
+    cfg = git_tiny(F)
+    w = synthetic_weights(cfg, 0)
+    g = np.load(os.path.join(golden_dir, f"hf_tiny_F{F}.npz"))
+    fr = make_frames(2, max(1, F), cfg.image_size, int(g["frame_seed"]))
+    orc = GitOracle(cfg, w)
+    vis, mem = orc.forward_image_enc(fr)
+    assert np.abs(vis.numpy() - g["visual"]).max() < 1e-4
+    assert np.abs(mem.numpy() - g["projected"]).max() < 1e-4
+    logits = orc.decoder_full(mem, torch.from_numpy(g["prefix_ids"]))
+    assert np.abs(logits.numpy() - g["logits"]).max() < 2e-4           # fp32 vs fp32, logit std ~4
+    for use_cache in (True, False):                                     # exact KV cache == full recompute
+        ids = orc.greedy_decode(fr, 8, stop="never", use_cache=use_cache)
+        assert np.array_equal(ids.numpy(), g["greedy_ids"])
+
+
+def test_tiny_kv_cache_equals_full_recompute_logits():
+    cfg = git_tiny(2)
+    orc = GitOracle(cfg, synthetic_weights(cfg, 0))
+    fr = make_frames(3, 2, cfg.image_size, 5)
+    _, a = orc.greedy_decode(fr, 6, stop="never", use_cache=True, return_logits=True)
+    _, b = orc.greedy_decode(fr, 6, stop="never", use_cache=False, return_logits=True)
+    assert (a - b).abs().max() < 1e-4
+
+
+def test_bf16_emulation_is_close_to_fp32():
+    cfg = git_tiny(2)
+    w = synthetic_weights(cfg, 0)
+    fr = make_frames(2, 2, cfg.image_size, 1234)
+    ids = torch.tensor([[101, 5, 9, 33], [101, 77, 3, 150]])
+    a, _ = GitOracle(cfg, w).forward_output_logits(fr, ids)
+    b, _ = GitOracle(cfg, w, emulate_bf16=True).forward_output_logits(fr, ids)
+    err = (a - b).abs().max().item()
+    assert 1e-4 < err < 0.05 * a.std().item(), err     # bf16 operands: visible, but small vs the logit spread
+
+
+def test_greedy_stop_rule_all_sep():
+    """model.py:184: stop only when ALL rows emit SEP in the same step; rows keep generating after
+    their own SEP.  Planted head bias makes SEP the argmax for every row."""
+    cfg = git_tiny(2)
+    w = synthetic_weights(cfg, 0)
+    w["head.b"] = w["head.b"].copy()
+    w["head.b"][cfg.sep_token_id] = 1e4
+    orc = GitOracle(cfg, w)
+    fr = make_frames(2, 2, cfg.image_size, 1)
+    ids = orc.greedy_decode(fr, 8, stop="all_sep")
+    assert ids.shape == (2, 2) and bool((ids[:, 1] == cfg.sep_token_id).all())
+    assert orc.greedy_decode(fr, 8, stop="never").shape == (2, 9)
+
+
+@pytest.mark.parametrize("F,name", [(0, "hf_base_F1.npz"), (6, "hf_base_F6.npz")])
+def test_base_oracle_matches_hf(golden_dir, F, name):
+    """GIT-base (176.6 M parameters), B=2: the 21 greedy ids, the top-8 logits of every step and a
+    slice of the visual features against the HF fp32 run."""
+    cfg = git_base(F)
+    w = synthetic_weights(cfg, 0)
+    g = np.load(os.path.join(golden_dir, name))
+    fr = make_frames(2, max(1, F), cfg.image_size, int(g["frame_seed"]))
+    orc = GitOracle(cfg, w)
+    vis, mem = orc.forward_image_enc(fr)
+    assert np.abs(vis[:, ::97, :32].numpy() - g["visual_slice"]).max() < 2e-4
+    # teacher-forced on the golden ids so that a near-tie cannot cascade
+    ids = torch.from_numpy(g["greedy_ids"])
+    logits = orc.decoder_full(mem, ids[:, :-1])
+    top = torch.gather(logits, 2, torch.from_numpy(g["greedy_top_ids"]))
+    assert np.abs(top.numpy() - g["greedy_top_vals"]).max() < 1e-3
+    assert np.abs(logits[:, :, :16].numpy() - g["greedy_last16"]).max() < 1e-3
+    margin = g["greedy_top_vals"][..., 0] - g["greedy_top_vals"][..., 1]
+    assert np.array_equal(logits.argmax(-1).numpy()[margin > 5e-3], ids[:, 1:].numpy()[margin > 5e-3])
