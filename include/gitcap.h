@@ -132,6 +132,18 @@ int gitcap_profile_enable(gitcap_t* h, int enable);
 int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launches,
                         double* flops_total, double* bytes_total);
 
+/* Kernel-level test hooks (tests/test_kernels_gpu.py, scratch/gemm_bench.py): run ONE kernel on
+ * caller-owned device buffers.  gemm: out[m][n] = sum_k A[m][k]*W[n][k] (+epilogue `epi` of
+ * csrc/kernels.h: 0 bias->bf16, 1 bias+QuickGELU->bf16, 2 bias+GELU->bf16, 3 bias+resid->f32,
+ * 4 bias->f32); A [M][K] bf16, W [N][K] bf16, M % 128 == 0; tile = 128 or 256. */
+int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float* resid, void* out,
+                    int M, int N, int K, int epi, int tile, void* stream);
+/* attn_full: qkv [G*S][3*H*64] bf16 -> ctx [G*S][H*64] bf16 */
+int gitcap_dbg_attn_full(const void* qkv, void* ctx, int G, int S, int H, void* stream);
+/* layernorm: x fp32 [rows][D] -> out_f32 / out_bf16 (either may be NULL) */
+int gitcap_dbg_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int D,
+                         float* out_f32, void* out_bf16, void* stream);
+
 /* Introspection used by tests and bench.py */
 int gitcap_workspace_bytes(const gitcap_t* h, int64_t* bytes);
 int gitcap_abi_version(void);

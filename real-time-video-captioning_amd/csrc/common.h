@@ -50,5 +50,22 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
-__device__ __forceinline__ float erf_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// x * sigmoid(1.702 x) with v_exp_f32 / v_rcp_f32 (each ~1 ulp; the result is rounded to bf16)
+__device__ __forceinline__ float quick_gelu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
+}
+// erf via Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the output):
+// erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1/(1 + p z), z >= 0; odd extension.
+__device__ __forceinline__ float fast_erf(float x) {
+    const float z = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    const float r = 1.0f - p * t * e;
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float erf_gelu(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }

@@ -1,0 +1,329 @@
+// 256x256x64-tile bf16 MFMA GEMM for gfx950 (the dominant kernel of the caption path).
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k]  (+ fused epilogue), A and W both K-contiguous.
+//
+// Why 256^2: a 128x128x64 tile needs 32 KiB of operands per 2.1 MFLOP, i.e. 64 B/clk/CU of
+// global->LDS fill at the MFMA peak, which is the whole L1/LDS-DMA rate of a CU; at 256^2 the same
+// ratio is 32 B/clk.  One workgroup (512 threads = 8 waves, 2 per SIMD) per CU, 128 KiB of LDS.
+//
+// Wave w = (wn = w >> 2, wm = w & 3) owns the 128(n) x 64(m) block of the tile; weight rows are the
+// MFMA A operand and activation rows the B operand (v_mfma_f32_16x16x32_bf16), so an accumulator
+// quad is 4 consecutive n of one m and the epilogue moves 8/16-byte vectors.
+//
+// Schedule ("ping-pong"): waves 0-3 (group 0) and waves 4-7 (group 1) share the SIMDs pairwise
+// and run the SAME program one barrier apart, so while one wave of a SIMD is in a LOAD phase
+// (ds_read_b128 fragment reads + LDS-DMA issue for the next K-tile) its partner is in a COMPUTE
+// phase (16 MFMAs = one 64x32 quadrant over K=64):
+//
+//     slot      8t+0   8t+1   8t+2   8t+3   8t+4   8t+5   8t+6   8t+7
+//     group 0   L0(t)  C0(t)  L1(t)  C1(t)  L2(t)  C2(t)  L3(t)  C3(t)
+//     group 1   C3(t-1) L0(t) C0(t)  L1(t)  C1(t)  L2(t)  C2(t)  L3(t)
+//
+//   L0: read W frags of rows N0 (8) + act frags M0 (4)
+//   L1: read act frags M1 (4);        LDS-DMA W-hi(t+1)
+//   L2: read W frags of rows N1 (8);  LDS-DMA A-lo(t+2)
+//   L3:                               LDS-DMA A-hi(t+2), W-lo(t+2); s_waitcnt vmcnt(6)
+//   quadrant order (N0,M0) (N0,M1) (N1,M1) (N1,M0): M0/M1 fragments stay in registers.
+// Every slot ends with one s_barrier executed by all 8 waves.  The LDS-DMA prefetch runs ~1.5
+// K-tiles ahead through only two stages: a half-tile of tile t is overwritten by tile t+2 as soon
+// as both groups are past its last read (A halves: L1(t); W halves: L2(t)).  RAW: the counted
+// vmcnt(6) in L3(t) retires every DMA of tile t+1 (the six youngest belong to tile t+2) and tile
+// t+1 is first read one barrier later; every LOAD phase drains lgkmcnt before its barrier (WAR).
+//
+// LDS image per stage (64 KiB): [W-lo | W-hi | A-lo | A-hi], each 128 rows x 128 B, 16-B chunks
+// XOR-swizzled by (row>>1)&7 on the DMA SOURCE address and again on the read (conflict-free
+// ds_read_b128 for the 16x16x32 operand map, see common.h).
+#include "kernels.h"
+
+namespace {
+
+constexpr int STAGE = 65536, HALF = 16384;
+constexpr int EPI_REGION = 64 * (64 * 4 + 16);   // per-wave epilogue staging (fp32 worst case): 17408 B
+constexpr int LDS_TOTAL = 8 * EPI_REGION;        // 139264 B >= 2 * STAGE
+
+#define BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2;                      // ping-pong group
+    const int wn = wid >> 2, wm = wid & 3;
+    const int ntn = a.N >> 8;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = lid / ntn, tn = lid - tm * ntn;
+    const int m0 = tm << 8, n0 = tn << 8;
+
+    // ---- LDS-DMA source addresses: wave w moves pieces 2w, 2w+1 (8 rows each) of every half-tile
+    const bf16_t* srcW[2];
+    const bf16_t* srcA[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wid * 2 + i) * 8 + (lane >> 3);            // row inside a 128-row half-tile
+        const int chunk = swz_chunk(row, lane & 7);
+        srcW[i] = a.W + (size_t)(n0 + row) * a.K + chunk * 8;
+        srcA[i] = a.A + (size_t)(m0 + row) * a.lda + chunk * 8;
+    }
+    const size_t hiW = (size_t)128 * a.K, hiA = (size_t)128 * a.lda;
+    const int dma_off = wid * 2048;                                  // this wave's pieces inside a half-tile
+
+    // ---- fragment read offsets (bytes inside a stage)
+    const int frow = lane & 15, fq = lane >> 4;
+    const int g = (frow >> 1) & 7;
+    const int offW = wn * HALF + frow * 128;                                        // + (Nh*64 + i*16)*128
+    const int offA = 2 * HALF + (wm >> 1) * HALF + ((wm & 1) * 64 + frow) * 128;     // + (Mh*32 + j*16)*128
+    const int c0 = ((0 + fq) ^ g) << 4, c1 = ((4 + fq) ^ g) << 4;                  // k-step 0 / 1 chunk offsets
+
+    f32x4 acc[2][4][2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[x][i][y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // one half-tile (2 DMA instructions per wave): which = 0 W-lo, 1 W-hi, 2 A-lo, 3 A-hi
+    auto dma_half = [&](char* stage, int which, int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16_t* src = (which < 2 ? srcW[i] + (which & 1) * hiW : srcA[i] + (which & 1) * hiA) + k0;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(stage + which * HALF + dma_off + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // Prefetch runs ~1.5 K-tiles ahead with the 8 DMA instructions of a tile spread over four LOAD
+    // phases (2 each), each issued as soon as BOTH groups have finished reading the half-tile it
+    // overwrites:   L2(t): A-lo(t+2)   L3(t): A-hi(t+2), W-lo(t+2)   L1(t+1): W-hi(t+2)
+    // (A halves are last read in L1(t), W halves in L2(t); group 1 trails group 0 by one slot.)
+    // The only wait is a COUNTED one in L3(t): vmcnt(6) leaves the six youngest DMAs (all of them
+    // for tile t+2) in flight and retires everything of tile t+1, which is first read one barrier
+    // later, in L0(t+1).
+    const int nt = a.K >> 6;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) dma_half(smem, w, 0);
+    if (nt > 1) {
+        dma_half(smem + STAGE, 2, 64);
+        dma_half(smem + STAGE, 3, 64);
+        dma_half(smem + STAGE, 0, 64);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        WAIT_VM0();
+    }
+    BARRIER();
+    if (grp == 1) BARRIER();                       // group 1 runs one slot behind group 0
+
+    bf16x8 wf[4][2], af[2][2][2];
+    for (int t = 0; t < nt; ++t) {
+        const char* sb = smem + (t & 1) * STAGE;
+        char* cb = smem + (t & 1) * STAGE;          // stage of tile t == stage of tile t+2
+        char* nb = smem + ((t + 1) & 1) * STAGE;
+        const bool has1 = (t + 1) < nt, has2 = (t + 2) < nt;
+        const int k1 = (t + 1) << 6, k2 = (t + 2) << 6;
+
+        // ---------------- L0: W rows N0, act rows M0 ---------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wf[i][0] = *(const bf16x8*)(sb + offW + i * 2048 + c0);
+            wf[i][1] = *(const bf16x8*)(sb + offW + i * 2048 + c1);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            af[0][j][0] = *(const bf16x8*)(sb + offA + j * 2048 + c0);
+            af[0][j][1] = *(const bf16x8*)(sb + offA + j * 2048 + c1);
+        }
+        WAIT_LGKM0();
+        SCHED_FENCE();
+        BARRIER();
+        // ---------------- C0: (N0, M0) -----------------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[0][i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], af[0][j][ks], acc[0][i][0][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        SCHED_FENCE();
+        BARRIER();
+        // ---------------- L1: act rows M1; DMA W-hi of tile t+1 ------------------------------------
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            af[1][j][0] = *(const bf16x8*)(sb + offA + 32 * 128 + j * 2048 + c0);
+            af[1][j][1] = *(const bf16x8*)(sb + offA + 32 * 128 + j * 2048 + c1);
+        }
+        if (has1) dma_half(nb, 1, k1);
+        WAIT_LGKM0();
+        SCHED_FENCE();
+        BARRIER();
+        // ---------------- C1: (N0, M1) -----------------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[0][i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], af[1][j][ks], acc[0][i][1][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        SCHED_FENCE();
+        BARRIER();
+        // ---------------- L2: W rows N1; DMA A-lo of tile t+2 --------------------------------------
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wf[i][0] = *(const bf16x8*)(sb + offW + 64 * 128 + i * 2048 + c0);
+            wf[i][1] = *(const bf16x8*)(sb + offW + 64 * 128 + i * 2048 + c1);
+        }
+        if (has2) dma_half(cb, 2, k2);
+        WAIT_LGKM0();
+        SCHED_FENCE();
+        BARRIER();
+        // ---------------- C2: (N1, M1) -----------------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[1][i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], af[1][j][ks], acc[1][i][1][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        SCHED_FENCE();
+        BARRIER();
+        // ---------------- L3: DMA A-hi, W-lo of tile t+2; retire tile t+1 ---------------------------
+        if (has2) {
+            dma_half(cb, 3, k2);
+            dma_half(cb, 0, k2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            WAIT_VM0();
+        }
+        SCHED_FENCE();
+        BARRIER();
+        // ---------------- C3: (N1, M0) -----------------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[1][i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], af[0][j][ks], acc[1][i][0][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        SCHED_FENCE();
+        BARRIER();
+    }
+    if (grp == 0) BARRIER();                       // matches group 1's extra leading barrier
+
+    // ---- epilogue through LDS ----------------------------------------------------------------------
+    // The accumulator layout (lane = one m, 4 consecutive n) would scatter 32-byte pieces over 16
+    // rows per store instruction.  Instead every wave transposes its 64(m) x 64(n) half-blocks through
+    // a private LDS region (the operand stages are dead after the last barrier) and writes/reads
+    // global memory as full row segments: 16 B per lane, 128 B (bf16) or 256 B (fp32) per row.
+    constexpr bool OUT_BF16 = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16);
+    constexpr int ESZ = OUT_BF16 ? 2 : 4;
+    constexpr int RS = 64 * ESZ + 16;                      // padded row stride (bytes)
+    constexpr int LPR = 64 * ESZ / 16;                     // lanes per row on the row-wise side (8 or 16)
+    constexpr int RPI = 64 / LPR;                          // rows per wave-instruction (8 or 4)
+    char* ep = smem + wid * EPI_REGION;
+    const int rr = lane / LPR, rc = lane % LPR;            // row-wise role of this lane
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int nb = n0 + wn * 128 + x * 64;             // first n of this half-block
+        // 1) accumulator layout -> LDS [m_local][n_local]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int nl = i * 16 + fq * 4;
+            f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (EPI != EPI_PATCH_F32 && a.bias) bias4 = *(const f32x4*)(a.bias + nb + nl);
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int ml = y * 32 + j * 16 + frow;
+                    f32x4 v = acc[x][i][y][j] + bias4;
+                    if (EPI == EPI_BIAS_QGELU_BF16) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
+                    } else if (EPI == EPI_BIAS_GELU_BF16) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = erf_gelu(v[r]);
+                    }
+                    if (OUT_BF16) {
+                        uint2 o;
+                        o.x = pack_bf2(v[0], v[1]);
+                        o.y = pack_bf2(v[2], v[3]);
+                        *(uint2*)(ep + ml * RS + nl * 2) = o;
+                    } else {
+                        *(f32x4*)(ep + ml * RS + nl * 4) = v;
+                    }
+                }
+        }
+        WAIT_LGKM0();
+        // 2) LDS rows -> global, 16 B per lane along n
+#pragma unroll
+        for (int it = 0; it < 64 / RPI; ++it) {
+            const int ml = it * RPI + rr;
+            const int m = m0 + wm * 64 + ml;
+            const int n = nb + rc * (16 / ESZ);
+            const uint4 raw = *(const uint4*)(ep + ml * RS + rc * 16);
+            if (OUT_BF16) {
+                *(uint4*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = raw;
+            } else {
+                f32x4 v = __builtin_bit_cast(f32x4, raw);
+                if (EPI == EPI_BIAS_RESID_F32) {
+                    v += *(const f32x4*)(a.resid + (size_t)m * a.ldr + n);
+                    *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;
+                } else if (EPI == EPI_BIAS_F32) {
+                    *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;
+                } else {  // EPI_PATCH_F32: m = frame*P + patch -> row frame*N + 1 + patch, + pos[1+patch]
+                    if (m < a.valid_rows) {
+                        const int frame = m / a.patches_per_frame;
+                        const int patch = m - frame * a.patches_per_frame;
+                        v += *(const f32x4*)(a.pos + (size_t)(1 + patch) * a.N + n);
+                        const size_t orow = (size_t)frame * a.tokens_per_frame + 1 + patch;
+                        *(f32x4*)((float*)a.out + orow * a.ldo + n) = v;
+                    }
+                }
+            }
+        }
+        WAIT_LGKM0();                                      // reads done before the next half-block overwrites
+    }
+}
+
+template <int EPI>
+hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = (a.M >> 8) * (a.N >> 8);
+    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS_TOTAL, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool gemm256_ok(const GemmArgs& a) { return a.M > 0 && (a.M & 255) == 0 && (a.N & 255) == 0 && (a.K & 63) == 0; }
+
+hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
+    if (!gemm256_ok(a)) return hipErrorInvalidValue;
+    switch (epi) {
+        case EPI_BIAS_BF16: return launch_t<EPI_BIAS_BF16>(a, s);
+        case EPI_BIAS_QGELU_BF16: return launch_t<EPI_BIAS_QGELU_BF16>(a, s);
+        case EPI_BIAS_GELU_BF16: return launch_t<EPI_BIAS_GELU_BF16>(a, s);
+        case EPI_BIAS_RESID_F32: return launch_t<EPI_BIAS_RESID_F32>(a, s);
+        case EPI_BIAS_F32: return launch_t<EPI_BIAS_F32>(a, s);
+        case EPI_PATCH_F32: return launch_t<EPI_PATCH_F32>(a, s);
+    }
+    return hipErrorInvalidValue;
+}

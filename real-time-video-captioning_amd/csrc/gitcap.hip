@@ -184,7 +184,7 @@ int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const bf16
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
     a.resid = resid; a.ldr = ldr;
-    HIP_OK(h, launch_gemm(a, epi, s));
+    HIP_OK(h, gemm256_ok(a) ? launch_gemm256(a, epi, s) : launch_gemm(a, epi, s));
     return 0;
 }
 
@@ -213,7 +213,7 @@ int ln_reduce(gitcap* h, hipStream_t s, const float* slabs, int nslab, const flo
 // projected image tokens -> decoder layers over image rows only; fills kv_img (text independent)
 int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
     const gitcap_config& c = h->c;
-    const int D = h->D, Dv = h->Dv, rows = B * S, Mp = pad_to(rows, 128);
+    const int D = h->D, Dv = h->Dv, rows = B * S, Mp = pad_to(rows, 256);
     int rc;
     h->prof_rows = rows;
     // 'linearLn' projection: Linear(Dv -> D) + LayerNorm
@@ -344,8 +344,8 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     h->Kp = pad_to(3 * c.patch_size * c.patch_size, 64);
     h->Dv = c.enc_width; h->D = c.dec_width; h->V = c.vocab_size; h->Vp = pad_to(c.vocab_size, 16);
     h->Smax = c.max_frames * h->N;
-    h->Mi = pad_to(c.max_batch * h->Smax, 128);
-    h->Pp = pad_to(c.max_batch * c.max_frames * h->G * h->G, 128);
+    h->Mi = pad_to(c.max_batch * h->Smax, 256);
+    h->Pp = pad_to(c.max_batch * c.max_frames * h->G * h->G, 256);
     h->R = c.max_batch * c.max_beams; h->Tmax = c.max_text_len;
     h->Mt = pad_to(h->R * h->Tmax, 16);
     const int Dm = std::max(h->Dv, h->D), Fm = std::max(c.enc_ffn, c.dec_ffn);
@@ -466,8 +466,8 @@ int gitcap_encode(gitcap_t* h, const float* frames, int B, int F, float* visual_
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const gitcap_config& c = h->c;
-    const int Dv = h->Dv, N = h->N, nf = B * F, rows = nf * N, Mp = pad_to(rows, 128);
-    const int P = nf * h->G * h->G, Pp = pad_to(P, 128);
+    const int Dv = h->Dv, N = h->N, nf = B * F, rows = nf * N, Mp = pad_to(rows, 256);
+    const int P = nf * h->G * h->G, Pp = pad_to(P, 256);
     h->have_image = false;
 
     // patchify (conv k = stride = p, no bias) + CLS + position embedding, then ln_pre
@@ -477,7 +477,7 @@ int gitcap_encode(gitcap_t* h, const float* frames, int B, int F, float* visual_
         GemmArgs a{};
         a.A = h->patches; a.lda = h->Kp; a.W = h->patch_w; a.bias = nullptr; a.M = Pp; a.N = Dv; a.K = h->Kp;
         a.out = h->x; a.ldo = Dv; a.pos = h->pos; a.tokens_per_frame = N; a.patches_per_frame = h->G * h->G; a.valid_rows = P;
-        HIP_OK(h, launch_gemm(a, EPI_PATCH_F32, s));
+        HIP_OK(h, gemm256_ok(a) ? launch_gemm256(a, EPI_PATCH_F32, s) : launch_gemm(a, EPI_PATCH_F32, s));
     }
     HIP_OK(h, launch_cls_rows(h->x, h->cls, h->pos, nf, N, Dv, s));
     h->prof_rows = rows;
@@ -581,6 +581,26 @@ int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launche
     if (bytes_total) *bytes_total = by;
     pc.used = 0;
     return 0;
+}
+
+int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float* resid, void* out, int M, int N, int K,
+                    int epi, int tile, void* stream) {
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.lda = K; a.W = (const bf16_t*)W; a.bias = bias; a.M = M; a.N = N; a.K = K;
+    a.out = out; a.ldo = N; a.resid = resid; a.ldr = N;
+    if (epi < 0 || epi > EPI_BIAS_F32) return GITCAP_ERR_ARG;
+    hipError_t e = (tile == 256) ? launch_gemm256(a, epi, (hipStream_t)stream) : launch_gemm(a, epi, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
+}
+
+int gitcap_dbg_attn_full(const void* qkv, void* ctx, int G, int S, int H, void* stream) {
+    return launch_attn_full((const bf16_t*)qkv, (bf16_t*)ctx, G, S, H, (hipStream_t)stream) == hipSuccess ? 0 : GITCAP_ERR_HIP;
+}
+
+int gitcap_dbg_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int D,
+                         float* out_f32, void* out_bf16, void* stream) {
+    LnArgs a{x, D, gamma, beta, eps, rows, D, out_f32, D, (bf16_t*)out_bf16, D, nullptr, 1, 1};
+    return launch_layernorm(a, (hipStream_t)stream) == hipSuccess ? 0 : GITCAP_ERR_HIP;
 }
 
 int gitcap_workspace_bytes(const gitcap_t* h, int64_t* bytes) {

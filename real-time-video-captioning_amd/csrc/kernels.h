@@ -21,7 +21,9 @@ struct GemmArgs {
     const float* pos;             // EPI_PATCH: [tokens_per_frame][N]
     int tokens_per_frame, patches_per_frame, valid_rows;
 };
-hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);
+hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);      // 128x128 tile (any M%128, N%128)
+bool gemm256_ok(const GemmArgs& a);
+hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);   // 256x256 tile, 8-wave ping-pong
 
 // ---- skinny GEMMs (text rows; M = a few 16-row tiles): weight streaming, one wave per tile ----
 enum SkinnyEpi { SK_BIAS_BF16 = 0, SK_BIAS_GELU_BF16 = 1, SK_BIAS_F32 = 3 };
