@@ -113,6 +113,17 @@ int gitcap_text_forward(gitcap_t* h, const int64_t* ids, int ld_ids, int rows, i
 int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, int stop,
                   int64_t* ids_out, int32_t* steps_out, void* stream);
 
+/* Pipelined form of gitcap_greedy for a stream of batches (no reference counterpart: the reference
+ * processes one clip at a time, src/models/model.py:765).  submit enqueues the image pass on the
+ * handle's encoder stream and the text loop on its decoder stream, ordered after the work already
+ * on `stream` (so `frames` may be produced there), and returns a ticket; at most TWO submissions may
+ * be in flight (two image-K/V slots), so batch i+1's MFMA-bound image pass overlaps batch i's
+ * latency-bound token loop.  wait makes `stream` wait for that submission's ids_out/steps_out.
+ * frames / ids_out / steps_out must stay valid until the wait. */
+int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max_len, int stop,
+                         int64_t* ids_out, int32_t* steps_out, void* stream, int* ticket);
+int gitcap_greedy_wait(gitcap_t* h, int ticket, void* stream);
+
 /* Beam reorder of the text part of the KV cache (what src/models/model.py:623-634 sketches):
  * new row r takes the cached text K/V of old row src_rows[r]; image K/V are shared. */
 int gitcap_reorder_rows(gitcap_t* h, const int32_t* src_rows, int rows, int t_len, void* stream);

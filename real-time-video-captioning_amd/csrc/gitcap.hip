@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -73,9 +74,21 @@ struct gitcap {
     std::vector<EncLayer> enc;
     std::vector<DecLayer> dec;
 
-    // state
+    // state of the selected image slot (views into slots[cur_slot]; see select_slot)
     int cur_B = 0, cur_S = 0;
     bool have_image = false;
+
+    // Two image slots (K/V of the image prefix + stop counters) let batch i+1's image pass run on
+    // `s_enc` while batch i's text loop runs on `s_txt` (gitcap_greedy_submit / _wait).  The
+    // synchronous entry points always use slot 0 on the caller's stream.
+    struct Slot {
+        bf16_t* kv_img = nullptr; int32_t* sep_cnt = nullptr;
+        int B = 0, S = 0; bool have = false, used = false;
+        hipEvent_t ev_in = nullptr, ev_enc = nullptr, ev_dec = nullptr;
+    };
+    Slot slots[2];
+    int cur_slot = 0, next_ticket = 0;
+    hipStream_t s_enc = nullptr, s_txt = nullptr;
     double prof_rows = 0;   // valid rows of the GEMMs being launched (set by the callers of gemm())
 
     // instrumentation (bench.py): HIP-event brackets per kernel class, on the launch stream
@@ -92,6 +105,14 @@ std::string g_create_err;
 int fail(const gitcap* h, int code, const std::string& msg) {
     if (h) h->err = msg; else g_create_err = msg;
     return code;
+}
+
+void select_slot(gitcap* h, int i) {
+    gitcap::Slot& o = h->slots[h->cur_slot];
+    o.B = h->cur_B; o.S = h->cur_S; o.have = h->have_image;
+    gitcap::Slot& n = h->slots[i];
+    h->kv_img = n.kv_img; h->sep_cnt = n.sep_cnt; h->cur_B = n.B; h->cur_S = n.S; h->have_image = n.have;
+    h->cur_slot = i;
 }
 
 #define HIP_OK(h, expr)                                                                               \
@@ -311,6 +332,8 @@ int check_frames(gitcap* h, const float* frames, int B, int F) {
 
 }  // namespace
 
+static int encode_impl(gitcap* h, const float* frames, int B, int F, float* visual_out, hipStream_t stream);
+
 extern "C" {
 
 int gitcap_abi_version(void) { return GITCAP_ABI_VERSION; }
@@ -370,6 +393,20 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     rc = rc ? rc : ws_alloc(h, &h->kv_txt, (size_t)c.dec_layers * h->R * h->Tmax * 3 * h->D);
     rc = rc ? rc : ws_alloc(h, &h->kv_txt2, (size_t)c.dec_layers * h->R * h->Tmax * 3 * h->D);
     rc = rc ? rc : ws_alloc(h, &h->sep_cnt, (size_t)h->Tmax + 1);
+    h->slots[0].kv_img = h->kv_img; h->slots[0].sep_cnt = h->sep_cnt;
+    rc = rc ? rc : ws_alloc(h, &h->slots[1].kv_img, (size_t)c.dec_layers * Mi * 3 * h->D);
+    rc = rc ? rc : ws_alloc(h, &h->slots[1].sep_cnt, (size_t)h->Tmax + 1);
+    if (!rc) {
+        // two plain non-blocking streams for the two-batch pipeline (stream priorities measured
+        // neutral and CU-masked streams 2.5x slower on this platform: DESIGN.md "What did not work")
+        bool ok = hipStreamCreateWithFlags(&h->s_enc, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&h->s_txt, hipStreamNonBlocking) == hipSuccess;
+        for (auto& sl : h->slots)
+            ok = ok && hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&sl.ev_enc, hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&sl.ev_dec, hipEventDisableTiming) == hipSuccess;
+        if (!ok) rc = fail(h, GITCAP_ERR_HIP, "create: stream/event creation failed");
+    }
     if (rc) {
         g_create_err = h->err;
         gitcap_destroy(h);
@@ -391,6 +428,13 @@ void gitcap_destroy(gitcap_t* h) {
     if (!h) return;
     for (auto& pc : h->prof)
         for (auto& r : pc.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto& sl : h->slots) {
+        if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
+        if (sl.ev_enc) (void)hipEventDestroy(sl.ev_enc);
+        if (sl.ev_dec) (void)hipEventDestroy(sl.ev_dec);
+    }
+    if (h->s_enc) (void)hipStreamDestroy(h->s_enc);
+    if (h->s_txt) (void)hipStreamDestroy(h->s_txt);
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto& kv : h->w)
         if (kv.second.p) (void)hipFree(kv.second.p);
@@ -462,9 +506,14 @@ int gitcap_finalize_weights(gitcap_t* h) {
 
 int gitcap_encode(gitcap_t* h, const float* frames, int B, int F, float* visual_out, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "encode: null handle");
+    select_slot(h, 0);
+    return encode_impl(h, frames, B, F, visual_out, (hipStream_t)stream);
+}
+
+static int encode_impl(gitcap* h, const float* frames, int B, int F, float* visual_out, hipStream_t stream) {
     int rc = check_frames(h, frames, B, F);
     if (rc) return rc;
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s = stream;
     const gitcap_config& c = h->c;
     const int Dv = h->Dv, N = h->N, nf = B * F, rows = nf * N, Mp = pad_to(rows, 256);
     const int P = nf * h->G * h->G, Pp = pad_to(P, 256);
@@ -508,6 +557,7 @@ int gitcap_encode(gitcap_t* h, const float* frames, int B, int F, float* visual_
 int gitcap_set_visual(gitcap_t* h, const float* visual, int B, int S_img, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "set_visual: null handle");
     if (!h->finalized) return fail(h, GITCAP_ERR_STATE, "weights not finalized");
+    select_slot(h, 0);
     if (!visual || B <= 0 || S_img <= 0) return fail(h, GITCAP_ERR_ARG, "set_visual: bad arguments");
     if (B > h->c.max_batch || S_img > h->Smax) return fail(h, GITCAP_ERR_ARG, "set_visual: B/S_img exceed the sizes the handle was created for");
     if (((uintptr_t)visual & 15) != 0) return fail(h, GITCAP_ERR_ARG, "set_visual: visual must be 16-byte aligned");
@@ -520,20 +570,14 @@ int gitcap_set_visual(gitcap_t* h, const float* visual, int B, int S_img, void* 
 int gitcap_text_forward(gitcap_t* h, const int64_t* ids, int ld_ids, int rows, int beams, int t0, int T,
                         float* logits_out, int all_positions, int64_t* argmax_out, int ld_argmax, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "text_forward: null handle");
+    select_slot(h, 0);
     return text_forward(h, ids, ld_ids, rows, beams, t0, T, logits_out, all_positions, argmax_out, ld_argmax, nullptr, 0,
                         (hipStream_t)stream);
 }
 
-int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, int stop, int64_t* ids_out,
-                  int32_t* steps_out, void* stream) {
-    if (!h) return fail(h, GITCAP_ERR_ARG, "greedy: null handle");
-    if (!ids_out || max_len <= 0) return fail(h, GITCAP_ERR_ARG, "greedy: bad arguments");
-    if (max_len > h->Tmax) return fail(h, GITCAP_ERR_ARG, "greedy: max_len exceeds max_text_len");
-    if (stop != GITCAP_STOP_NEVER && stop != GITCAP_STOP_ALL_SEP) return fail(h, GITCAP_ERR_ARG, "greedy: unknown stop rule");
-    hipStream_t s = (hipStream_t)stream;
-    int rc = gitcap_encode(h, frames, B, F, nullptr, stream);
-    if (rc) return rc;
+static int greedy_text_loop(gitcap* h, int B, int max_len, int stop, int64_t* ids_out, int32_t* steps_out, hipStream_t s) {
     const int ld = max_len + 1;
+    int rc;
     // CLS start tokens [B,1] (model.py:171)
     HIP_OK(h, launch_fill_i64(ids_out, ld, B, h->c.cls_token_id, s));
     HIP_OK(h, hipMemsetAsync(h->sep_cnt, 0, ((size_t)h->Tmax + 1) * 4, s));
@@ -543,6 +587,55 @@ int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, i
         if (rc) return rc;
     }
     if (steps_out) HIP_OK(h, launch_finish_steps(h->sep_cnt, B, max_len, stop, steps_out, s));
+    return 0;
+}
+
+static int greedy_check(gitcap* h, int max_len, int stop, const int64_t* ids_out) {
+    if (!ids_out || max_len <= 0) return fail(h, GITCAP_ERR_ARG, "greedy: bad arguments");
+    if (max_len > h->Tmax) return fail(h, GITCAP_ERR_ARG, "greedy: max_len exceeds max_text_len");
+    if (stop != GITCAP_STOP_NEVER && stop != GITCAP_STOP_ALL_SEP) return fail(h, GITCAP_ERR_ARG, "greedy: unknown stop rule");
+    return 0;
+}
+
+int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, int stop, int64_t* ids_out,
+                  int32_t* steps_out, void* stream) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "greedy: null handle");
+    int rc = greedy_check(h, max_len, stop, ids_out);
+    if (rc) return rc;
+    select_slot(h, 0);
+    if ((rc = encode_impl(h, frames, B, F, nullptr, (hipStream_t)stream))) return rc;
+    return greedy_text_loop(h, B, max_len, stop, ids_out, steps_out, (hipStream_t)stream);
+}
+
+int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max_len, int stop, int64_t* ids_out,
+                         int32_t* steps_out, void* stream, int* ticket) {
+    if (!h || !ticket) return fail(h, GITCAP_ERR_ARG, "greedy_submit: null argument");
+    int rc = greedy_check(h, max_len, stop, ids_out);
+    if (rc) return rc;
+    const int slot = h->next_ticket & 1;
+    gitcap::Slot& sl = h->slots[slot];
+    select_slot(h, slot);
+    // the image pass may start once the caller's stream has produced `frames` ...
+    HIP_OK(h, hipEventRecord(sl.ev_in, (hipStream_t)stream));
+    HIP_OK(h, hipStreamWaitEvent(h->s_enc, sl.ev_in, 0));
+    // ... and once the previous user of this slot's image K/V (two submissions ago) has finished decoding
+    if (sl.used) HIP_OK(h, hipStreamWaitEvent(h->s_enc, sl.ev_dec, 0));
+    if ((rc = encode_impl(h, frames, B, F, nullptr, h->s_enc))) return rc;
+    HIP_OK(h, hipEventRecord(sl.ev_enc, h->s_enc));
+    HIP_OK(h, hipStreamWaitEvent(h->s_txt, sl.ev_enc, 0));
+    if ((rc = greedy_text_loop(h, B, max_len, stop, ids_out, steps_out, h->s_txt))) return rc;
+    HIP_OK(h, hipEventRecord(sl.ev_dec, h->s_txt));
+    sl.used = true;
+    *ticket = h->next_ticket++;
+    select_slot(h, 0);
+    return 0;
+}
+
+int gitcap_greedy_wait(gitcap_t* h, int ticket, void* stream) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "greedy_wait: null handle");
+    if (ticket < 0 || ticket >= h->next_ticket || ticket < h->next_ticket - 2)
+        return fail(h, GITCAP_ERR_ARG, "greedy_wait: ticket is not one of the two submissions in flight");
+    HIP_OK(h, hipStreamWaitEvent((hipStream_t)stream, h->slots[ticket & 1].ev_dec, 0));
     return 0;
 }
 

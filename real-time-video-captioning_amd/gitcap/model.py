@@ -31,6 +31,27 @@ from . import weights as W
 STOP_NEVER, STOP_ALL_SEP = 0, 1
 
 
+class CaptionFuture:
+    """Handle of one gitcap_greedy_submit; keeps the device buffers alive until result()."""
+
+    def __init__(self, model, ticket, ids, steps, frames, mode, out_device):
+        self._m, self._ticket, self._ids, self._steps = model, ticket, ids, steps
+        self._frames, self._mode, self._out_device = frames, mode, out_device
+        self._done = False
+
+    def result(self) -> torch.Tensor:
+        m = self._m
+        if not self._done:
+            with torch.cuda.device(m._dev):
+                m._call("gitcap_greedy_wait", self._ticket, m._stream())
+            self._done = True
+            self._frames = None
+        ids = self._ids
+        if self._mode == STOP_ALL_SEP:
+            ids = ids[:, :1 + int(self._steps.item())]
+        return ids.to(self._out_device) if self._out_device != ids.device else ids
+
+
 def _rebuild(cfg_dict, weights, kwargs):
     return GitCaptioner(GitCapConfig(**cfg_dict), weights, **kwargs)
 
@@ -252,6 +273,30 @@ class GitCaptioner(nn.Module):
         return ids.to(src.device) if src.device != ids.device else ids
 
     generate = greedy_decode      # the name BASELINE.json's north_star uses for this entry point
+
+    @torch.no_grad()
+    def greedy_decode_async(self, src: torch.Tensor, max_len: int = 10, stop: Optional[str] = None) -> "CaptionFuture":
+        """Pipelined greedy_decode for a stream of batches: returns immediately with a future; up to
+        TWO batches may be in flight, so the next batch's image pass (MFMA bound) overlaps this
+        batch's token loop (latency bound) on the handle's two internal HIP streams.  Call
+        ``.result()`` (in submission order) to make the current stream wait and get the ids."""
+        stop = stop or self.stop
+        mode = {"all_sep": STOP_ALL_SEP, "never": STOP_NEVER}[stop]
+        if max_len > self.max_text_len:
+            raise ValueError(f"max_len {max_len} > max_text_len={self.max_text_len} the handle was created for")
+        fr = self._frames(src)
+        B, F = fr.shape[:2]
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} > max_batch={self.max_batch}")
+        with torch.cuda.device(self._dev):
+            ids = torch.empty((B, max_len + 1), dtype=torch.int64, device=self._dev)
+            steps = torch.zeros((1,), dtype=torch.int32, device=self._dev)
+            ticket = ctypes.c_int(-1)
+            self._call("gitcap_greedy_submit", ctypes.c_void_p(fr.data_ptr()), B, F, max_len, mode,
+                       ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(steps.data_ptr()), self._stream(),
+                       ctypes.byref(ticket))
+        self._last_memory = None
+        return CaptionFuture(self, ticket.value, ids, steps, fr, mode, src.device)
 
     @torch.no_grad()
     def step_logits(self, ids_last: torch.Tensor, t: int, beams: int = 1) -> torch.Tensor:

@@ -205,6 +205,26 @@ def test_errors_are_loud(captioner_cls):
         bare.greedy_decode(make_frames(1, 2, cfg.image_size, 0), max_len=2)
 
 
+def test_pipelined_submit_matches_synchronous(captioner_cls):
+    """gitcap_greedy_submit/_wait (two batches in flight on the library's streams) must give exactly
+    the ids of the one-batch-at-a-time path."""
+    cfg = git_tiny(2)
+    m = captioner_cls(cfg, synthetic_weights(cfg, 0), max_batch=4, max_text_len=8)
+    batches = [make_frames(4, 2, cfg.image_size, 100 + i).cuda() for i in range(5)]
+    want = [m.greedy_decode(b, max_len=8, stop="never").clone() for b in batches]
+    got, pending = [], None
+    for b in batches:
+        fut = m.greedy_decode_async(b, max_len=8, stop="never")
+        if pending is not None:
+            got.append(pending.result())
+        pending = fut
+    got.append(pending.result())
+    torch.cuda.synchronize()
+    for a, b in zip(want, got):
+        assert torch.equal(a, b)
+    assert torch.equal(m.greedy_decode(batches[0], max_len=8, stop="never"), want[0])   # sync path still fine afterwards
+
+
 def test_pickle_roundtrip(captioner_cls):
     """real_time_inference.py:8-9 does torch.load() of a pickled whole module."""
     cfg = git_tiny(2)
