@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--serial", action="store_true", help="one batch at a time (no cross-batch pipelining)")
+    ap.add_argument("--inflight", type=int, default=4, choices=(2, 3, 4), help="batches in flight when pipelined")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,8 +114,8 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    # K steps = K batches.  Default: two batches in flight (batch i+1's image pass overlaps batch i's
-    # token loop on the library's two streams); every batch is submitted AND completed (ids gathered)
+    # K steps = K batches.  Default: four batches in flight (one image pass overlaps the token loops of
+    # the batches before it, on the library's streams); every batch is submitted AND completed (ids gathered)
     # inside the timed region.  --serial runs one batch at a time.
     ev_sub = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_done = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -125,16 +126,17 @@ def main():
             out = step()
             ev_done[i].record()
     else:
-        pending = None
+        pending = []
         for i in range(args.steps):
             ev_sub[i].record()
-            fut = model.greedy_decode_async(frames, max_len=TOKENS, stop="never")
-            if pending is not None:
-                out = finish(pending[1].result())
-                ev_done[pending[0]].record()
-            pending = (i, fut)
-        out = finish(pending[1].result())
-        ev_done[pending[0]].record()
+            pending.append((i, model.greedy_decode_async(frames, max_len=TOKENS, stop="never")))
+            if len(pending) == args.inflight:
+                j, fut = pending.pop(0)
+                out = finish(fut.result())
+                ev_done[j].record()
+        for j, fut in pending:
+            out = finish(fut.result())
+            ev_done[j].record()
     fence()
     elapsed = time.perf_counter() - t0
     lat = sorted(ev_sub[i].elapsed_time(ev_done[i]) for i in range(args.steps))   # submit -> ids ready, per batch
@@ -144,6 +146,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, p50 = float(t[0]), float(t[1])
     assert out.shape == (world * CLIPS_PER_GPU, TOKENS + 1)
+
+    # ---- unpipelined reference point: one batch at a time (what a single real-time caller sees) ----
+    serial = None
+    if not args.serial:
+        ns = min(args.steps, 10)
+        es = [torch.cuda.Event(enable_timing=True) for _ in range(ns + 1)]
+        fence()
+        es[0].record()
+        for i in range(ns):
+            step()
+            es[i + 1].record()
+        fence()
+        sl = sorted(es[i].elapsed_time(es[i + 1]) for i in range(ns))
+        serial = {"captions_per_s_per_gpu": round(CLIPS_PER_GPU / (sum(sl) / ns * 1e-3), 1), "p50_latency_ms": round(sl[ns // 2], 3)}
 
     # ---- per-kernel-class timing: HIP events recorded by the library on its launch stream ----
     roofline, breakdown = None, None
@@ -185,9 +201,9 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: batch=16 6-frame 224x224 clips per GPU, GIT-base "
                                    "(ViT-B/16 + 6-layer decoder), 20-token greedy, EOS disabled",
                        "clips_per_gpu": CLIPS_PER_GPU, "frames": FRAMES, "tokens": TOKENS, "global_batch": world * CLIPS_PER_GPU,
-                       "parallelism": f"dp{world}", "batches_in_flight": 1 if args.serial else 2, "collective": "all_gather(int64[16,21]) per step" if world > 1 else "none"},
+                       "parallelism": f"dp{world}", "batches_in_flight": 1 if args.serial else args.inflight, "collective": "all_gather(int64[16,21]) per step" if world > 1 else "none"},
             "caption_mfma_frac": round(value / world * GFLOP_PER_CAPTION / 1e3 / MFMA_PEAK_TFLOPS, 4),
-            "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown,
+            "serial": serial, "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

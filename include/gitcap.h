@@ -116,9 +116,9 @@ int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, i
 /* Pipelined form of gitcap_greedy for a stream of batches (no reference counterpart: the reference
  * processes one clip at a time, src/models/model.py:765).  submit enqueues the image pass on the
  * handle's encoder stream and the text loop on its decoder stream, ordered after the work already
- * on `stream` (so `frames` may be produced there), and returns a ticket; at most TWO submissions may
- * be in flight (two image-K/V slots), so batch i+1's MFMA-bound image pass overlaps batch i's
- * latency-bound token loop.  wait makes `stream` wait for that submission's ids_out/steps_out.
+ * on `stream` (so `frames` may be produced there), and returns a ticket; at most FOUR submissions
+ * may be in flight (four slots), so one batch's MFMA-bound image pass overlaps the latency-bound
+ * token loops of the batches before it.  wait makes `stream` wait for that submission's ids_out/steps_out.
  * frames / ids_out / steps_out must stay valid until the wait. */
 int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max_len, int stop,
                          int64_t* ids_out, int32_t* steps_out, void* stream, int* ticket);

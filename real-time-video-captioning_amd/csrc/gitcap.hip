@@ -78,17 +78,23 @@ struct gitcap {
     int cur_B = 0, cur_S = 0;
     bool have_image = false;
 
-    // Two image slots (K/V of the image prefix + stop counters) let batch i+1's image pass run on
-    // `s_enc` while batch i's text loop runs on `s_txt` (gitcap_greedy_submit / _wait).  The
-    // synchronous entry points always use slot 0 on the caller's stream.
+    // Four slots (image-prefix K/V, text-row workspace, stop counters, decode stream): while batch
+    // i+2's image pass (MFMA bound) runs on `s_enc`, the token loops of batches i and i+1 (chains of
+    // tiny latency-bound kernels) of the batches before it interleave on their own streams (gitcap_greedy_submit / _wait).
+    // The synchronous entry points always use slot 0 on the caller's stream.
     struct Slot {
         bf16_t* kv_img = nullptr; int32_t* sep_cnt = nullptr;
+        // text-row workspace of the slot (each slot's token loop runs on its own stream)
+        float *xs = nullptr, *slabs = nullptr, *amax_val = nullptr; int* amax_idx = nullptr;
+        bf16_t *xsb = nullptr, *cs = nullptr, *fs = nullptr, *kv_txt = nullptr, *kv_txt2 = nullptr;
         int B = 0, S = 0; bool have = false, used = false;
         hipEvent_t ev_in = nullptr, ev_enc = nullptr, ev_dec = nullptr;
+        hipStream_t s_txt = nullptr;
     };
-    Slot slots[2];
+    static constexpr int NSLOT = 4;
+    Slot slots[NSLOT];
     int cur_slot = 0, next_ticket = 0;
-    hipStream_t s_enc = nullptr, s_txt = nullptr;
+    hipStream_t s_enc = nullptr;
     double prof_rows = 0;   // valid rows of the GEMMs being launched (set by the callers of gemm())
 
     // instrumentation (bench.py): HIP-event brackets per kernel class, on the launch stream
@@ -110,8 +116,11 @@ int fail(const gitcap* h, int code, const std::string& msg) {
 void select_slot(gitcap* h, int i) {
     gitcap::Slot& o = h->slots[h->cur_slot];
     o.B = h->cur_B; o.S = h->cur_S; o.have = h->have_image;
+    o.kv_txt = h->kv_txt; o.kv_txt2 = h->kv_txt2;        // reorder_rows swaps these two
     gitcap::Slot& n = h->slots[i];
     h->kv_img = n.kv_img; h->sep_cnt = n.sep_cnt; h->cur_B = n.B; h->cur_S = n.S; h->have_image = n.have;
+    h->xs = n.xs; h->slabs = n.slabs; h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
+    h->xsb = n.xsb; h->cs = n.cs; h->fs = n.fs; h->kv_txt = n.kv_txt; h->kv_txt2 = n.kv_txt2;
     h->cur_slot = i;
 }
 
@@ -383,26 +392,32 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     rc = rc ? rc : ws_alloc(h, &h->ffn, Mi * Fm);
     rc = rc ? rc : ws_alloc(h, &h->patches, (size_t)h->Pp * h->Kp);
     rc = rc ? rc : ws_alloc(h, &h->kv_img, (size_t)c.dec_layers * Mi * 3 * h->D);
-    rc = rc ? rc : ws_alloc(h, &h->xs, Mt * h->D);
-    rc = rc ? rc : ws_alloc(h, &h->slabs, (size_t)16 * Mt * h->D);
-    rc = rc ? rc : ws_alloc(h, &h->xsb, Mt * h->D);
-    rc = rc ? rc : ws_alloc(h, &h->cs, Mt * h->D);
-    rc = rc ? rc : ws_alloc(h, &h->fs, Mt * c.dec_ffn);
-    rc = rc ? rc : ws_alloc(h, &h->amax_val, Mt * (size_t)((h->V + 15) / 16));
-    rc = rc ? rc : ws_alloc(h, &h->amax_idx, Mt * (size_t)((h->V + 15) / 16));
-    rc = rc ? rc : ws_alloc(h, &h->kv_txt, (size_t)c.dec_layers * h->R * h->Tmax * 3 * h->D);
-    rc = rc ? rc : ws_alloc(h, &h->kv_txt2, (size_t)c.dec_layers * h->R * h->Tmax * 3 * h->D);
-    rc = rc ? rc : ws_alloc(h, &h->sep_cnt, (size_t)h->Tmax + 1);
-    h->slots[0].kv_img = h->kv_img; h->slots[0].sep_cnt = h->sep_cnt;
-    rc = rc ? rc : ws_alloc(h, &h->slots[1].kv_img, (size_t)c.dec_layers * Mi * 3 * h->D);
-    rc = rc ? rc : ws_alloc(h, &h->slots[1].sep_cnt, (size_t)h->Tmax + 1);
+    for (int i = 0; i < gitcap::NSLOT && !rc; ++i) {
+        gitcap::Slot& sl = h->slots[i];
+        if (i == 0) sl.kv_img = h->kv_img;
+        else rc = rc ? rc : ws_alloc(h, &sl.kv_img, (size_t)c.dec_layers * Mi * 3 * h->D);
+        rc = rc ? rc : ws_alloc(h, &sl.sep_cnt, (size_t)h->Tmax + 1);
+        rc = rc ? rc : ws_alloc(h, &sl.xs, Mt * h->D);
+        rc = rc ? rc : ws_alloc(h, &sl.slabs, (size_t)16 * Mt * h->D);
+        rc = rc ? rc : ws_alloc(h, &sl.xsb, Mt * h->D);
+        rc = rc ? rc : ws_alloc(h, &sl.cs, Mt * h->D);
+        rc = rc ? rc : ws_alloc(h, &sl.fs, Mt * c.dec_ffn);
+        rc = rc ? rc : ws_alloc(h, &sl.amax_val, Mt * (size_t)((h->V + 15) / 16));
+        rc = rc ? rc : ws_alloc(h, &sl.amax_idx, Mt * (size_t)((h->V + 15) / 16));
+        rc = rc ? rc : ws_alloc(h, &sl.kv_txt, (size_t)c.dec_layers * h->R * h->Tmax * 3 * h->D);
+        rc = rc ? rc : ws_alloc(h, &sl.kv_txt2, (size_t)c.dec_layers * h->R * h->Tmax * 3 * h->D);
+    }
+    if (!rc) {   // select slot 0
+        gitcap::Slot& n = h->slots[0];
+        h->sep_cnt = n.sep_cnt; h->xs = n.xs; h->slabs = n.slabs; h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
+        h->xsb = n.xsb; h->cs = n.cs; h->fs = n.fs; h->kv_txt = n.kv_txt; h->kv_txt2 = n.kv_txt2;
+    }
     if (!rc) {
-        // two plain non-blocking streams for the two-batch pipeline (stream priorities measured
-        // neutral and CU-masked streams 2.5x slower on this platform: DESIGN.md "What did not work")
-        bool ok = hipStreamCreateWithFlags(&h->s_enc, hipStreamNonBlocking) == hipSuccess &&
-                  hipStreamCreateWithFlags(&h->s_txt, hipStreamNonBlocking) == hipSuccess;
+        // plain non-blocking streams for the pipeline (stream priorities measured neutral and
+        // CU-masked streams 2.5x slower on this platform: DESIGN.md "What did not work")
+        bool ok = hipStreamCreateWithFlags(&h->s_enc, hipStreamNonBlocking) == hipSuccess;
         for (auto& sl : h->slots)
-            ok = ok && hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming) == hipSuccess &&
+            ok = ok && hipStreamCreateWithFlags(&sl.s_txt, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&sl.ev_enc, hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&sl.ev_dec, hipEventDisableTiming) == hipSuccess;
         if (!ok) rc = fail(h, GITCAP_ERR_HIP, "create: stream/event creation failed");
@@ -432,9 +447,9 @@ void gitcap_destroy(gitcap_t* h) {
         if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
         if (sl.ev_enc) (void)hipEventDestroy(sl.ev_enc);
         if (sl.ev_dec) (void)hipEventDestroy(sl.ev_dec);
+        if (sl.s_txt) (void)hipStreamDestroy(sl.s_txt);
     }
     if (h->s_enc) (void)hipStreamDestroy(h->s_enc);
-    if (h->s_txt) (void)hipStreamDestroy(h->s_txt);
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto& kv : h->w)
         if (kv.second.p) (void)hipFree(kv.second.p);
@@ -612,7 +627,7 @@ int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max
     if (!h || !ticket) return fail(h, GITCAP_ERR_ARG, "greedy_submit: null argument");
     int rc = greedy_check(h, max_len, stop, ids_out);
     if (rc) return rc;
-    const int slot = h->next_ticket & 1;
+    const int slot = h->next_ticket % gitcap::NSLOT;
     gitcap::Slot& sl = h->slots[slot];
     select_slot(h, slot);
     // the image pass may start once the caller's stream has produced `frames` ...
@@ -622,9 +637,9 @@ int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max
     if (sl.used) HIP_OK(h, hipStreamWaitEvent(h->s_enc, sl.ev_dec, 0));
     if ((rc = encode_impl(h, frames, B, F, nullptr, h->s_enc))) return rc;
     HIP_OK(h, hipEventRecord(sl.ev_enc, h->s_enc));
-    HIP_OK(h, hipStreamWaitEvent(h->s_txt, sl.ev_enc, 0));
-    if ((rc = greedy_text_loop(h, B, max_len, stop, ids_out, steps_out, h->s_txt))) return rc;
-    HIP_OK(h, hipEventRecord(sl.ev_dec, h->s_txt));
+    HIP_OK(h, hipStreamWaitEvent(sl.s_txt, sl.ev_enc, 0));
+    if ((rc = greedy_text_loop(h, B, max_len, stop, ids_out, steps_out, sl.s_txt))) return rc;
+    HIP_OK(h, hipEventRecord(sl.ev_dec, sl.s_txt));
     sl.used = true;
     *ticket = h->next_ticket++;
     select_slot(h, 0);
@@ -633,9 +648,9 @@ int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max
 
 int gitcap_greedy_wait(gitcap_t* h, int ticket, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "greedy_wait: null handle");
-    if (ticket < 0 || ticket >= h->next_ticket || ticket < h->next_ticket - 2)
-        return fail(h, GITCAP_ERR_ARG, "greedy_wait: ticket is not one of the two submissions in flight");
-    HIP_OK(h, hipStreamWaitEvent((hipStream_t)stream, h->slots[ticket & 1].ev_dec, 0));
+    if (ticket < 0 || ticket >= h->next_ticket || ticket < h->next_ticket - gitcap::NSLOT)
+        return fail(h, GITCAP_ERR_ARG, "greedy_wait: ticket is not one of the submissions in flight");
+    HIP_OK(h, hipStreamWaitEvent((hipStream_t)stream, h->slots[ticket % gitcap::NSLOT].ev_dec, 0));
     return 0;
 }
 

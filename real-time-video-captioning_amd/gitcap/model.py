@@ -277,8 +277,8 @@ class GitCaptioner(nn.Module):
     @torch.no_grad()
     def greedy_decode_async(self, src: torch.Tensor, max_len: int = 10, stop: Optional[str] = None) -> "CaptionFuture":
         """Pipelined greedy_decode for a stream of batches: returns immediately with a future; up to
-        TWO batches may be in flight, so the next batch's image pass (MFMA bound) overlaps this
-        batch's token loop (latency bound) on the handle's two internal HIP streams.  Call
+        FOUR batches may be in flight, so one batch's image pass (MFMA bound) overlaps the token
+        loops (latency bound) of the batches before it on the handle's internal HIP streams.  Call
         ``.result()`` (in submission order) to make the current stream wait and get the ids."""
         stop = stop or self.stop
         mode = {"all_sep": STOP_ALL_SEP, "never": STOP_NEVER}[stop]
