@@ -113,6 +113,14 @@ int gitcap_text_forward(gitcap_t* h, const int64_t* ids, int ld_ids, int rows, i
 int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, int stop,
                   int64_t* ids_out, int32_t* steps_out, void* stream);
 
+/* Replaces: F.log_softmax(scores) + beam_scores, view(B, beams*V), torch.topk(2*beams)
+ *                                                         src/models/model.py:557-565
+ * logits: device fp32 [B*beams][ld]; beam_scores: device fp32 [B*beams]; outputs: device
+ * out_scores fp32 [B][K], out_idx int32 [B][K] (flat index beam*V + word), sorted descending,
+ * ties by smaller flat index; K <= 16, beams <= 16.  Stateless (no handle). */
+int gitcap_beam_topk(const float* logits, int ld, const float* beam_scores, int B, int beams, int V, int K,
+                     float* out_scores, int32_t* out_idx, void* stream);
+
 /* Pipelined form of gitcap_greedy for a stream of batches (no reference counterpart: the reference
  * processes one clip at a time, src/models/model.py:765).  submit enqueues the image pass on the
  * handle's encoder stream and the text loop on its decoder stream, ordered after the work already

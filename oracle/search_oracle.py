@@ -1,0 +1,127 @@
+"""CPU oracle of the GIT search operator.  TEST INFRASTRUCTURE ONLY (see oracle/git_oracle.py).
+
+Restates, in plain Python/torch, ``GeneratorWithBeamSearchV2.search``
+(/root/reference/src/models/model.py:479-678) and the ``BeamHypotheses`` container it instantiates
+(:503).  ``BeamHypotheses`` itself lives in the absent ``generativeimage2text`` package (model.py:15);
+it is the XLM/HF container whose published algorithm is: keep the ``n_hyp`` best finished
+hypotheses ranked by ``sum_logprobs / len(hyp) ** length_penalty``; ``is_done(best_sum_logprobs)``
+is False while fewer than ``n_hyp`` are stored, True if ``early_stopping``, otherwise
+``worst_score >= best_sum_logprobs / max_length ** length_penalty``.
+
+PARITY: unpinned by the reference (no test or fixture exercises the search, SURVEY.md par. 4); this
+restatement is checked against exhaustive enumeration on small problems (tests/test_search.py).
+Defaults mirror model.py:702-708 (beam 4, max_steps 15, length_penalty 0.6) and the upstream
+constructor default per_node_beam_size = 2.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Tuple
+
+import torch
+import torch.nn.functional as F
+
+
+class BeamHypotheses:
+    def __init__(self, n_hyp: int, max_length: int, length_penalty: float, early_stopping: bool):
+        self.max_length = max_length - 1          # ignoring bos
+        self.length_penalty = length_penalty
+        self.early_stopping = early_stopping
+        self.n_hyp = n_hyp
+        self.hyp: List[Tuple[float, torch.Tensor]] = []
+        self.worst_score = 1e9
+
+    def __len__(self):
+        return len(self.hyp)
+
+    def add(self, hyp: torch.Tensor, sum_logprobs: float):
+        score = sum_logprobs / len(hyp) ** self.length_penalty
+        if len(self) < self.n_hyp or score > self.worst_score:
+            self.hyp.append((score, hyp))
+            if len(self) > self.n_hyp:
+                sorted_scores = sorted([(s, idx) for idx, (s, _) in enumerate(self.hyp)])
+                del self.hyp[sorted_scores[0][1]]
+                self.worst_score = sorted_scores[1][0]
+            else:
+                self.worst_score = min(score, self.worst_score)
+
+    def is_done(self, best_sum_logprobs: float) -> bool:
+        if len(self) < self.n_hyp:
+            return False
+        if self.early_stopping:
+            return True
+        return self.worst_score >= best_sum_logprobs / self.max_length ** self.length_penalty
+
+
+def beam_search(input_ids: torch.Tensor, step: Callable[[torch.Tensor], torch.Tensor], *, eos_index: int,
+                max_steps: int = 15, beam_size: int = 4, per_node_beam_size: int = 2,
+                length_penalty: float = 0.6, num_keep_best: int = 1):
+    """Greedy-beam branch of model.py:479-678 (do_sample=False, repetition_penalty=1, temperature=1).
+    ``step(ids[B*beams, cur_len]) -> logits[B*beams, V]`` of the last position (model.py:519).
+    Returns (decoded [B, max_steps] padded with EOS, logprobs [B, num_keep_best], saved_logits)."""
+    batch_size, cur_len = input_ids.shape
+    num_beams, pad_token_id = beam_size, eos_index
+    input_ids = input_ids.unsqueeze(1).expand(batch_size, num_beams, cur_len).contiguous().view(batch_size * num_beams, cur_len)
+    max_length = max_steps                                                             # :500
+    hyps = [BeamHypotheses(num_keep_best, max_length, length_penalty, early_stopping=False) for _ in range(batch_size)]
+    beam_scores = torch.zeros((batch_size, num_beams), dtype=torch.float)
+    beam_scores[:, 1:] = -1e9                                                          # :509
+    beam_scores = beam_scores.view(-1)
+    done = [False] * batch_size
+    saved_logits = []
+    while cur_len < max_length:                                                        # :518
+        scores = step(input_ids)
+        vocab = scores.shape[-1]
+        saved_logits.append(scores.detach().clone())
+        scores = F.log_softmax(scores.float(), dim=-1)                                 # :557
+        _scores = (scores + beam_scores[:, None]).view(batch_size, num_beams * vocab)  # :561-563
+        next_scores, next_words = torch.topk(_scores, per_node_beam_size * num_beams, dim=1, largest=True, sorted=True)
+        next_batch_beam = []
+        for b in range(batch_size):                                                    # :573
+            done[b] = done[b] or hyps[b].is_done(next_scores[b].max().item())
+            if done[b]:
+                next_batch_beam.extend([(0, pad_token_id, 0)] * num_beams)
+                continue
+            next_sent_beam = []
+            for idx, score in zip(next_words[b], next_scores[b]):
+                beam_id, word_id = int(idx) // vocab, int(idx) % vocab
+                if word_id == eos_index or cur_len + 1 == max_length:                  # :592
+                    hyps[b].add(input_ids[b * num_beams + beam_id, :cur_len].clone(), score.item())
+                else:
+                    next_sent_beam.append((score, word_id, b * num_beams + beam_id))
+                if len(next_sent_beam) == num_beams:
+                    break
+            if cur_len + 1 == max_length:
+                assert len(next_sent_beam) == 0
+            else:
+                assert len(next_sent_beam) == num_beams
+            if len(next_sent_beam) == 0:
+                next_sent_beam = [(0, pad_token_id, 0)] * num_beams
+            next_batch_beam.extend(next_sent_beam)
+        beam_scores = torch.tensor([float(x[0]) for x in next_batch_beam])
+        beam_words = torch.tensor([x[1] for x in next_batch_beam], dtype=torch.long)
+        beam_idx = torch.tensor([x[2] for x in next_batch_beam], dtype=torch.long)
+        input_ids = torch.cat([input_ids[beam_idx, :], beam_words.unsqueeze(1)], dim=-1)   # :620-621
+        cur_len += 1
+        if all(done):
+            break
+    tgt_len = torch.ones(batch_size, num_keep_best, dtype=torch.long)                 # :653
+    logprobs = torch.full((batch_size, num_keep_best), -1e5)
+    all_best = []
+    for i, h in enumerate(hyps):
+        best = []
+        hyp_scores = torch.tensor([x[0] for x in h.hyp])
+        _, best_idx = torch.topk(hyp_scores, min(num_keep_best, len(hyp_scores)), largest=True)
+        for bi, hi in enumerate(best_idx):
+            conf, best_hyp = h.hyp[hi]
+            best.append(best_hyp)
+            logprobs[i, bi] = conf
+            tgt_len[i, bi] = len(best_hyp) + 1
+        all_best.append(best)
+    decoded = torch.full((batch_size, num_keep_best, max_length), pad_token_id, dtype=torch.long)
+    for b, best in enumerate(all_best):
+        for bi, hypo in enumerate(best):
+            decoded[b, bi, : tgt_len[b, bi] - 1] = hypo
+            decoded[b, bi, tgt_len[b, bi] - 1] = eos_index
+    if num_keep_best == 1:
+        decoded = decoded.squeeze(1)
+    return decoded, logprobs, saved_logits

@@ -18,6 +18,7 @@
 //   streaming straight to VGPRs, 8 lanes per key row (16 B each), per-8-lane-group online softmax
 //   state so the inner loop has no cross-group traffic; groups and waves are merged at the end.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -25,9 +26,10 @@ constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+template <int NST>
 __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict__ qkv,
                                                         bf16_t* __restrict__ ctx, int S, int H) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * 16384];   // per stage: K 8 KiB | V 8 KiB
+    __shared__ __attribute__((aligned(16))) char lds[NST * 16384];   // per stage: K 8 KiB | V 8 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int head = blockIdx.y, grp = blockIdx.z;
@@ -74,7 +76,9 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
     // ---- per-lane read offsets
     // K operand rows: key (32*kt + l31), chunk (2*ks + h2) swizzled by g(row); 32-aligned bases keep g = (l31>>1)&7
     const int kg = (l31 >> 1) & 7;
-    const int k_off = l31 * 128;
+    int koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * 128 + (((2 * ks + h2) ^ kg) << 4);
     // V transposed reads: 16-lane group (dgrp = (lane>>4)&1, h2); lane i=lane&15 supplies row i>>2, cols 4*(i&3)
     const int v_off = 8192 + (4 * h2 + ((lane & 15) >> 2)) * 64 + (((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2;
 
@@ -84,28 +88,54 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
     for (int r = 0; r < 16; ++r) { o_acc[0][r] = 0.f; o_acc[1][r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
+    // NST-stage LDS ring, LDS-DMA prefetch NST-1 tiles ahead.  A tile is 4 DMA instructions per
+    // wave, so "tile t has landed" is the counted wait vmcnt(4 * tiles issued beyond t); the raw
+    // s_barrier then (a) publishes every wave's pieces of tile t and (b) proves every wave is done
+    // with tile t-1, whose stage the next DMA overwrites.
     const int ntiles = (S + 63) >> 6;
-    stage(0, 0);
+#pragma unroll
+    for (int i = 0; i < NST - 1; ++i)
+        if (i < ntiles) stage(i, i * 64);
     for (int t = 0; t < ntiles; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < ntiles) stage((t + 1) & 1, (t + 1) * 64);
+        const int ahead = min(NST - 2, ntiles - 1 - t);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + NST - 1 < ntiles) stage((t + NST - 1) % NST, (t + NST - 1) * 64);
         if (!wave_active) continue;
-        const char* sb = lds + (t & 1) * 16384;
+        const char* sb = lds + (t % NST) * 16384;
         const int key0 = t * 64;
 
-        // ---- S^T = K . Q^T -----------------------------------------------------------------
+        // ---- S^T = K . Q^T : all 8 K fragments are requested before the first MFMA -----------------
+        bf16x8 kf[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *(const bf16x8*)(sb + kt * 4096 + koff[ks]);
         f32x16 s_acc[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s_acc[kt][r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(sb + kt * 4096 + k_off + (((2 * ks + h2) ^ kg) << 4));
-                s_acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s_acc[kt], 0, 0, 0);
-            }
+            for (int ks = 0; ks < 4; ++ks)
+                s_acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[ks], s_acc[kt], 0, 0, 0);
         }
+        // ---- V^T fragments: requested now, consumed after the softmax (latency hidden under VALU) ---
+        bf16x4 vlo[2][2][2], vhi[2][2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const char* vp = sb + v_off + dt * 4096 + (32 * kt + 16 * s2) * 64;
+                    vlo[kt][s2][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(vp));
+                    vhi[kt][s2][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(vp + 8 * 64));
+                }
         // ---- mask the ragged last tile (wave-uniform branch) ---------------------------------
         if (key0 + 64 > S) {
 #pragma unroll
@@ -136,24 +166,28 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
                 psum += p;
             }
         l_run = l_run * alpha + psum;
-        m_run = m_new;
+        // O only needs rescaling when some query's running max moved (rare after the first tiles);
+        // the branch is wave-uniform and exact (alpha == 1 for every lane otherwise)
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o_acc[0][r] *= alpha; o_acc[1][r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o_acc[0][r] *= alpha; o_acc[1][r] *= alpha; }
+        }
+        m_run = m_new;
 
         // ---- O^T += V^T . P^T -----------------------------------------------------------------
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 pf;
+                // 8 probabilities -> one bf16x8 B fragment (4 x v_cvt_pk_bf16_f32)
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                u32x4 pk;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (short)f2bf(s_acc[kt][8 * s + j]);
+                for (int j = 0; j < 4; ++j) pk[j] = pack_bf2(s_acc[kt][8 * s + 2 * j], s_acc[kt][8 * s + 2 * j + 1]);
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    const char* vp = sb + v_off + dt * 4096 + (32 * kt + 16 * s) * 64;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(vp));
-                    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(vp + 8 * 64));
-                    const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 vf = __builtin_shufflevector(vlo[kt][s][dt], vhi[kt][s][dt], 0, 1, 2, 3, 4, 5, 6, 7);
                     o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[dt], 0, 0, 0);
                 }
             }
@@ -222,9 +256,9 @@ __global__ __launch_bounds__(1024) void attn_text_kernel(TextAttnArgs a) {
 #pragma unroll
     for (int d = 0; d < 8; ++d) st.o[d] = 0.f;
 
-    for (int g0 = wid * 32; g0 < Lk; g0 += 16 * 32) {
-        bf16x8 kf[4], vf[4];
-        bool valid[4];
+    // Each wave owns only 2-3 groups of 32 keys, so the K/V load latency would be fully exposed:
+    // the loads of group i+1 are issued before group i is reduced (two register sets, static names).
+    auto load_group = [&](int g0, bf16x8* kf, bf16x8* vf, bool* valid) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             int key = g0 + u * 8 + kk;
@@ -234,6 +268,8 @@ __global__ __launch_bounds__(1024) void attn_text_kernel(TextAttnArgs a) {
             kf[u] = *(const bf16x8*)kp;
             vf[u] = *(const bf16x8*)(kp + D);
         }
+    };
+    auto reduce_group = [&](const bf16x8* kf, const bf16x8* vf, const bool* valid) {
         float sc[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -261,6 +297,21 @@ __global__ __launch_bounds__(1024) void attn_text_kernel(TextAttnArgs a) {
                 for (int d = 0; d < 8; ++d) st.o[d] += pb * bf2f((bf16_t)vf[u][d]);
             }
             st.m = m_new;
+        }
+    };
+    {
+        bf16x8 kA[4], vA[4], kB[4], vB[4];
+        bool okA[4], okB[4];
+        int g0 = wid * 32;
+        if (g0 < Lk) load_group(g0, kA, vA, okA);
+        while (g0 < Lk) {
+            if (g0 + 512 < Lk) load_group(g0 + 512, kB, vB, okB);
+            reduce_group(kA, vA, okA);
+            g0 += 512;
+            if (g0 >= Lk) break;
+            if (g0 + 512 < Lk) load_group(g0 + 512, kA, vA, okA);
+            reduce_group(kB, vB, okB);
+            g0 += 512;
         }
     }
     // merge the 8 key-groups of the wave (lanes with equal sub)
@@ -297,7 +348,10 @@ __global__ __launch_bounds__(1024) void attn_text_kernel(TextAttnArgs a) {
 hipError_t launch_attn_full(const bf16_t* qkv, bf16_t* ctx, int G, int S, int H, hipStream_t s) {
     if (G <= 0 || S <= 0 || H <= 0) return hipErrorInvalidValue;
     dim3 grid((S + 127) / 128, H, G);
-    hipLaunchKernelGGL(attn_full_kernel, grid, dim3(256), 0, s, qkv, ctx, S, H);
+    static const int nst = getenv("GITCAP_ATTN_NST") ? atoi(getenv("GITCAP_ATTN_NST")) : 2;
+    if (nst == 2) hipLaunchKernelGGL(attn_full_kernel<2>, grid, dim3(256), 0, s, qkv, ctx, S, H);
+    else if (nst == 4) hipLaunchKernelGGL(attn_full_kernel<4>, grid, dim3(256), 0, s, qkv, ctx, S, H);
+    else hipLaunchKernelGGL(attn_full_kernel<3>, grid, dim3(256), 0, s, qkv, ctx, S, H);
     return hipGetLastError();
 }
 

@@ -22,7 +22,10 @@ __device__ __forceinline__ float bf2f(bf16_t h) {
     return __builtin_bit_cast(float, (unsigned)h << 16);
 }
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    const bf16x2_t v = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);   // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(unsigned, v);
 }
 
 // 16-byte-chunk XOR swizzle for [rows][64 bf16] (128-B row) LDS tiles read with ds_read_b128 by

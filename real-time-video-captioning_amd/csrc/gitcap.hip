@@ -691,6 +691,13 @@ int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launche
     return 0;
 }
 
+int gitcap_beam_topk(const float* logits, int ld, const float* beam_scores, int B, int beams, int V, int K,
+                     float* out_scores, int32_t* out_idx, void* stream) {
+    if (!logits || !beam_scores || !out_scores || !out_idx) return GITCAP_ERR_ARG;
+    hipError_t e = launch_beam_topk(logits, ld, beam_scores, B, beams, V, K, out_scores, out_idx, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : (e == hipErrorInvalidValue ? GITCAP_ERR_ARG : GITCAP_ERR_HIP);
+}
+
 int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float* resid, void* out, int M, int N, int K,
                     int epi, int tile, void* stream) {
     GemmArgs a{};

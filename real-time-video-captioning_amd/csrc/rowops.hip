@@ -260,6 +260,77 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restri
     }
 }
 
+// ---- beam candidates: top-K of (log_softmax(logits[b*beams+j]) + beam_score[b*beams+j]) over j, v ----
+// One block per batch element.  Replaces log_softmax (:557) + add (:561) + view + topk (:563-565) of
+// the reference search loop (src/models/model.py); flat index = j*V + v, sorted descending, ties by
+// smaller flat index.
+template <int KMAX>
+__global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict__ logits, int ld,
+                                                        const float* __restrict__ beam_scores, int beams, int V, int K,
+                                                        float* __restrict__ out_scores, int* __restrict__ out_idx) {
+    __shared__ float red[4];
+    __shared__ int redi[4];
+    __shared__ float lse[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int j = 0; j < beams; ++j) {                                  // log-sum-exp of every beam row
+        const float* row = logits + (size_t)(b * beams + j) * ld;
+        float m = -INFINITY;
+        for (int i = tid; i < V; i += 256) m = fmaxf(m, row[i]);
+        m = wave_max(m);
+        if (lane == 0) red[wid] = m;
+        __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        float s = 0.f;
+        for (int i = tid; i < V; i += 256) s += expf(row[i] - m);
+        s = wave_sum(s);
+        if (lane == 0) red[wid] = s;
+        __syncthreads();
+        if (tid == 0) lse[j] = m + logf(red[0] + red[1] + red[2] + red[3]);
+        __syncthreads();
+    }
+    float tv[KMAX];
+    int ti[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { tv[k] = -INFINITY; ti[k] = 0x7fffffff; }
+    for (int j = 0; j < beams; ++j) {
+        const float* row = logits + (size_t)(b * beams + j) * ld;
+        const float add = beam_scores[b * beams + j] - lse[j];
+        for (int i = tid; i < V; i += 256) {
+            float v = row[i] + add;
+            int id = j * V + i;
+            if (v > tv[KMAX - 1]) {                                     // ascending ids per thread: strict > keeps the earlier one
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    if (v > tv[k]) { const float fv = tv[k]; const int fi = ti[k]; tv[k] = v; ti[k] = id; v = fv; id = fi; }
+                }
+            }
+        }
+    }
+    for (int k = 0; k < K; ++k) {                                      // K rounds of block arg-max over the list heads
+        float bv = tv[0];
+        int bi = ti[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(bv, o);
+            const int i2 = __shfl_xor(bi, o);
+            if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+        }
+        if (lane == 0) { red[wid] = bv; redi[wid] = bi; }
+        __syncthreads();
+        bv = red[0]; bi = redi[0];
+        for (int w = 1; w < 4; ++w)
+            if (red[w] > bv || (red[w] == bv && redi[w] < bi)) { bv = red[w]; bi = redi[w]; }
+        if (tid == 0) { out_scores[b * K + k] = bv; out_idx[b * K + k] = bi; }
+        if (ti[0] == bi) {                                               // the owner pops its head
+#pragma unroll
+            for (int q = 0; q + 1 < KMAX; ++q) { tv[q] = tv[q + 1]; ti[q] = ti[q + 1]; }
+            tv[KMAX - 1] = -INFINITY; ti[KMAX - 1] = 0x7fffffff;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- argmax: one block per row; lowest index wins ties (torch.argmax on CPU) -------------------
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int ld, int V,
                                                      int64_t* __restrict__ out, int ld_out,
@@ -346,6 +417,14 @@ hipError_t launch_argmax_final(const float* amax_val, const int* amax_idx, int n
                                int64_t* out, int ld_out, int32_t* sep_cnt, int step, int sep_id, hipStream_t s) {
     hipLaunchKernelGGL(argmax_final_kernel, dim3(rows), dim3(256), 0, s, amax_val, amax_idx, ntiles, row_stride, row_off,
                        out, ld_out, sep_cnt, step, sep_id);
+    return hipGetLastError();
+}
+
+hipError_t launch_beam_topk(const float* logits, int ld, const float* beam_scores, int B, int beams, int V, int K,
+                            float* out_scores, int* out_idx, hipStream_t s) {
+    if (B <= 0 || beams <= 0 || beams > 16 || K <= 0 || K > 16 || K > beams * V) return hipErrorInvalidValue;
+    if (K <= 8) hipLaunchKernelGGL(beam_topk_kernel<8>, dim3(B), dim3(256), 0, s, logits, ld, beam_scores, beams, V, K, out_scores, out_idx);
+    else hipLaunchKernelGGL(beam_topk_kernel<16>, dim3(B), dim3(256), 0, s, logits, ld, beam_scores, beams, V, K, out_scores, out_idx);
     return hipGetLastError();
 }
 

@@ -310,6 +310,40 @@ class GitCaptioner(nn.Module):
                        ctypes.c_void_p(logits.data_ptr()), 0, None, 0, self._stream())
         return logits
 
+    @torch.no_grad()
+    def infer(self, src: torch.Tensor, beam_size: int = 4, max_steps: int = 15, length_penalty: float = 0.6,
+              per_node_beam_size: int = 2, num_keep_best: int = 1, save_logits: bool = False) -> dict:
+        """GIT inference with beam search = ``GenerativeImageTextModel.infer`` (model.py:426-462) driven by
+        ``GeneratorWithBeamSearchV2.search`` (model.py:479-678; defaults of :702-708).  Returns the
+        reference's output dict: predictions [B, max_steps] (CLS-prefixed, EOS padded), logprobs [B,1],
+        logits_dict (per-step [B*beams, V] host arrays when save_logits, cf. :521) and visual_features."""
+        from .search import GeneratorWithBeamSearch
+        if beam_size > self.max_beams:
+            raise ValueError(f"beam_size {beam_size} > max_beams={self.max_beams} the handle was created for")
+        if max_steps > self.max_text_len:
+            raise ValueError(f"max_steps {max_steps} > max_text_len={self.max_text_len}")
+        fr = self._frames(src)
+        _, vis = self.forward_image_enc(fr)
+        B = fr.shape[0]
+        searcher = GeneratorWithBeamSearch(self.sep_token_id, max_steps, beam_size, per_node_beam_size, length_penalty)
+        start = torch.full((B, 1), self.cls_token_id, dtype=torch.long, device=self._dev)      # model.py:429-431
+
+        def step(ids):                       # decoding_step bound at model.py:442-445, KV-cached
+            return self.step_logits(ids[:, -1], ids.shape[1] - 1, beams=beam_size)
+
+        def reorder(beam_idx, cur_len):      # what model.py:623-634 leaves commented out
+            self.reorder_rows(beam_idx, cur_len)
+
+        decoded, logprobs, saved = searcher.search(start, step, num_keep_best=num_keep_best, reorder=reorder,
+                                                   save_logits=save_logits)
+        return {"predictions": decoded, "logprobs": logprobs, "logits_dict": saved, "visual_features": vis}
+
+    def beam_search(self, src: torch.Tensor, max_len: int = 10, k: int = 3) -> torch.Tensor:
+        """Signature of StudentCandidateV1.beam_search (model.py:189): best sequence per clip
+        [B, max_len], found with the GIT search operator (length penalty 0.6, model.py:702-708)."""
+        out = self.infer(src, beam_size=k, max_steps=max_len)["predictions"]
+        return out.to(src.device) if src.device != out.device else out
+
     def reorder_rows(self, src_rows: torch.Tensor, t_len: int):
         """Beam reorder of the text K/V cache (what model.py:623-634 sketches in comments)."""
         idx = src_rows.to(device=self._dev, dtype=torch.int32).contiguous()

@@ -1,0 +1,14 @@
+import ctypes, torch
+def run(libpath, G, S, H, iters=20):
+    lib = ctypes.CDLL(libpath); W = H * 64
+    qkv = (torch.randn(G * S, 3 * W, device='cuda') * 1.5).bfloat16(); ctx = torch.zeros(G * S, W, device='cuda', dtype=torch.bfloat16)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    call = lambda: lib.gitcap_dbg_attn_full(ctypes.c_void_p(qkv.data_ptr()), ctypes.c_void_p(ctx.data_ptr()), G, S, H, st)
+    assert call() == 0; torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): call()
+    e1.record(); torch.cuda.synchronize()
+    return round(e0.elapsed_time(e1) / iters * 1e3, 1)
+libs = {'full': 'real-time-video-captioning_amd/gitcap/libgitcap.so', 'noexp': 'scratch/libgitcap_v1.so', 'noPV': 'scratch/libgitcap_v2.so', 'noQK': 'scratch/libgitcap_v3.so', 'nobarrier': 'scratch/libgitcap_v4.so'}
+print({k: run(v, 16, 1182, 12) for k, v in libs.items()})
