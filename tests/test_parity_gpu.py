@@ -234,3 +234,24 @@ def test_pickle_roundtrip(captioner_cls):
     m2 = pickle.loads(pickle.dumps(m))
     m2.eval()
     assert torch.equal(m2.greedy_decode(fr, max_len=6, stop="never"), a)
+
+
+def test_git_large_config_vs_oracle(captioner_cls):
+    """GIT-large teacher shape (CLIPViT_L_14, visual_feature_size 1024: parameter.yaml:1-3): ViT-L/14,
+    24 layers, 16 heads, 257 tokens/frame, patch 14 (patch-embed K = 588 padded to 640)."""
+    from gitcap.config import git_large
+    cfg = git_large(num_frames=2)
+    w = synthetic_weights(cfg, 0)
+    fr = make_frames(1, 2, cfg.image_size, 77)
+    m = captioner_cls(cfg, w, max_batch=1, max_text_len=8)
+    emul = GitOracle(cfg, w, emulate_bf16=True)
+    _, vis = m.forward_image_enc(fr)
+    v_e = emul.encode_frames(fr)
+    assert vis.shape == (1, 2 * 257, 1024)
+    assert (vis.cpu() - v_e).abs().max() < 0.06, float((vis.cpu() - v_e).abs().max())
+    ids = torch.tensor([[101, 2023, 2003, 1037]])
+    lg = m.forward_decoder(ids, vis).cpu()
+    l_e, _ = emul.forward_output_logits(fr, ids)
+    assert (lg - l_e).abs().max() < LOGIT_TOL_EMUL * 1.5, float((lg - l_e).abs().max())
+    out = m.greedy_decode(fr, max_len=6, stop="never").cpu()
+    _tokens_match_margin_gated(out, emul, fr)
