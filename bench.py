@@ -176,8 +176,17 @@ def main():
         gm = prof["gemm"]
         avg_ms = gm["ms"] / max(1, gm["launches"])
         achieved = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
-        roofline = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        # HBM-side bytes per launch of this kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE,
+        # WRITE_SIZE; gfx950 x2 fetch correction) recorded in profiles/: bench.py cannot profile itself
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get("traffic_bytes_per_launch")
+            traffic_src = "profiles/r01_pmc_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --serial)"
+        roofline = {"bound": "mfma", "kernel": "gemm256_kernel", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": traffic_src,
                     "launches_per_step": gm["launches"] // nprof, "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_gflop_per_launch": round(gm["flops"] / max(1, gm["launches"]) / 1e9, 2)}
         sk, at = prof["skinny"], prof["attn_text"]

@@ -28,11 +28,27 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 
 template <int NST>
 __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict__ qkv,
-                                                        bf16_t* __restrict__ ctx, int S, int H) {
+                                                        bf16_t* __restrict__ ctx, int S, int H, int G, int nqb) {
     __shared__ __attribute__((aligned(16))) char lds[NST * 16384];   // per stage: K 8 KiB | V 8 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int head = blockIdx.y, grp = blockIdx.z;
+    // 1-D grid, XCD-aware: workgroups are dealt round-robin over the 8 XCDs (id % 8), each with a
+    // private L2.  All q-blocks of one (group, head) read the same K/V, so they are given ids with the
+    // same id % 8 (measured before this remap: 249 MB fetched beyond L2 per launch vs 87 MB of qkv).
+    // Placement only affects speed.
+    int qb, pair;
+    {
+        const int id = blockIdx.x, npairs = H * G;
+        if ((npairs & 7) == 0) {
+            const int slot = id >> 3;
+            pair = (slot / nqb) * 8 + (id & 7);
+            qb = slot - (slot / nqb) * nqb;
+        } else {
+            pair = id / nqb;
+            qb = id - pair * nqb;
+        }
+    }
+    const int head = pair % H, grp = pair / H;
     const int W = H * 64, ld = 3 * W;
     const size_t row0 = (size_t)grp * S;
     const bf16_t* qbase = qkv + row0 * ld + head * 64;
@@ -40,7 +56,7 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
     const bf16_t* vbase = qbase + 2 * W;
 
     const int l31 = lane & 31, h2 = lane >> 5;
-    const int q0 = blockIdx.x * 128 + wid * 32;
+    const int q0 = qb * 128 + wid * 32;
     const int q = q0 + l31;
     const bool wave_active = q0 < S;                 // wave-uniform
 
@@ -347,11 +363,12 @@ __global__ __launch_bounds__(1024) void attn_text_kernel(TextAttnArgs a) {
 
 hipError_t launch_attn_full(const bf16_t* qkv, bf16_t* ctx, int G, int S, int H, hipStream_t s) {
     if (G <= 0 || S <= 0 || H <= 0) return hipErrorInvalidValue;
-    dim3 grid((S + 127) / 128, H, G);
+    const int nqb = (S + 127) / 128;
+    dim3 grid(nqb * H * G);
     static const int nst = getenv("GITCAP_ATTN_NST") ? atoi(getenv("GITCAP_ATTN_NST")) : 2;
-    if (nst == 2) hipLaunchKernelGGL(attn_full_kernel<2>, grid, dim3(256), 0, s, qkv, ctx, S, H);
-    else if (nst == 4) hipLaunchKernelGGL(attn_full_kernel<4>, grid, dim3(256), 0, s, qkv, ctx, S, H);
-    else hipLaunchKernelGGL(attn_full_kernel<3>, grid, dim3(256), 0, s, qkv, ctx, S, H);
+    if (nst == 2) hipLaunchKernelGGL(attn_full_kernel<2>, grid, dim3(256), 0, s, qkv, ctx, S, H, G, nqb);
+    else if (nst == 4) hipLaunchKernelGGL(attn_full_kernel<4>, grid, dim3(256), 0, s, qkv, ctx, S, H, G, nqb);
+    else hipLaunchKernelGGL(attn_full_kernel<3>, grid, dim3(256), 0, s, qkv, ctx, S, H, G, nqb);
     return hipGetLastError();
 }
 
