@@ -107,6 +107,9 @@ struct gitcap {
 namespace {
 
 std::string g_create_err;
+// persistent-tile GEMM (gemm256p.hip) is an opt-in experiment: +2-5 % on multi-round shapes, slower on
+// the fp32-residual epilogue (DESIGN.md "What did not work")
+const bool g_persist = getenv("GITCAP_GEMM_PERSIST") && atoi(getenv("GITCAP_GEMM_PERSIST")) != 0;
 
 int fail(const gitcap* h, int code, const std::string& msg) {
     if (h) h->err = msg; else g_create_err = msg;
@@ -214,7 +217,7 @@ int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const bf16
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
     a.resid = resid; a.ldr = ldr;
-    HIP_OK(h, gemm256_ok(a) ? launch_gemm256(a, epi, s) : launch_gemm(a, epi, s));
+    HIP_OK(h, gemm256_ok(a) ? (g_persist ? launch_gemm256p(a, epi, s) : launch_gemm256(a, epi, s)) : launch_gemm(a, epi, s));
     return 0;
 }
 
@@ -541,7 +544,7 @@ static int encode_impl(gitcap* h, const float* frames, int B, int F, float* visu
         GemmArgs a{};
         a.A = h->patches; a.lda = h->Kp; a.W = h->patch_w; a.bias = nullptr; a.M = Pp; a.N = Dv; a.K = h->Kp;
         a.out = h->x; a.ldo = Dv; a.pos = h->pos; a.tokens_per_frame = N; a.patches_per_frame = h->G * h->G; a.valid_rows = P;
-        HIP_OK(h, gemm256_ok(a) ? launch_gemm256(a, EPI_PATCH_F32, s) : launch_gemm(a, EPI_PATCH_F32, s));
+        HIP_OK(h, gemm256_ok(a) ? (g_persist ? launch_gemm256p(a, EPI_PATCH_F32, s) : launch_gemm256(a, EPI_PATCH_F32, s)) : launch_gemm(a, EPI_PATCH_F32, s));
     }
     HIP_OK(h, launch_cls_rows(h->x, h->cls, h->pos, nf, N, Dv, s));
     h->prof_rows = rows;
@@ -704,7 +707,8 @@ int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float
     a.A = (const bf16_t*)A; a.lda = K; a.W = (const bf16_t*)W; a.bias = bias; a.M = M; a.N = N; a.K = K;
     a.out = out; a.ldo = N; a.resid = resid; a.ldr = N;
     if (epi < 0 || epi > EPI_BIAS_F32) return GITCAP_ERR_ARG;
-    hipError_t e = (tile == 256) ? launch_gemm256(a, epi, (hipStream_t)stream) : launch_gemm(a, epi, (hipStream_t)stream);
+    hipError_t e = (tile == 257) ? launch_gemm256p(a, epi, (hipStream_t)stream)
+                 : (tile == 256) ? launch_gemm256(a, epi, (hipStream_t)stream) : launch_gemm(a, epi, (hipStream_t)stream);
     return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
 }
 

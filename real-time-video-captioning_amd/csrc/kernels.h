@@ -24,6 +24,7 @@ struct GemmArgs {
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);      // 128x128 tile (any M%128, N%128)
 bool gemm256_ok(const GemmArgs& a);
 hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);   // 256x256 tile, 8-wave ping-pong
+hipError_t launch_gemm256p(const GemmArgs& a, int epi, hipStream_t s);  // same, persistent over tiles
 
 // ---- skinny GEMMs (text rows; M = a few 16-row tiles): weight streaming, one wave per tile ----
 enum SkinnyEpi { SK_BIAS_BF16 = 0, SK_BIAS_GELU_BF16 = 1, SK_BIAS_F32 = 3 };

@@ -25,7 +25,7 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [128, 256, 257])      # 257 = persistent 256x256 kernel
 @pytest.mark.parametrize("M,N,K,epi", [(512, 768, 768, 0), (256, 256, 64, 4), (768, 2304, 768, 0),
                                        (512, 3072, 768, 1), (512, 3072, 768, 2), (512, 768, 3072, 3),
                                        (256, 1536, 768, 0), (1024, 1024, 1024, 3)])
@@ -57,7 +57,7 @@ def test_gemm_identity_weight_asymmetric_input(lib):
     M = N = K = 256
     A = torch.arange(M * K, device="cuda", dtype=torch.float32).reshape(M, K).remainder(251).bfloat16()
     W = torch.eye(N, K, device="cuda").bfloat16()
-    for tile in (128, 256):
+    for tile in (128, 256, 257):
         out = torch.empty(M, N, device="cuda", dtype=torch.float32)
         assert lib.gitcap_dbg_gemm(_p(A), _p(W), None, None, _p(out), M, N, K, 4, tile, _stream()) == 0
         assert torch.equal(out, A.float())
