@@ -113,6 +113,14 @@ int gitcap_text_forward(gitcap_t* h, const int64_t* ids, int ld_ids, int rows, i
 int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, int stop,
                   int64_t* ids_out, int32_t* steps_out, void* stream);
 
+/* Replaces: image_transform()                          src/utils/dataloader.py:18-32
+ *                                                         src/real_time_inference.py:16-28
+ * ToTensor -> Resize(crop, bicubic, tensor path) -> CenterCrop(crop) -> BGR->RGB -> Normalize(CLIP),
+ * applied on the device to nf raw frames: frames_hwc_bgr device uint8 [nf][H][W][3] (OpenCV layout,
+ * real_time_inference.py:39) -> out_nchw device fp32 [nf][3][crop][crop], the layout gitcap_encode reads.
+ * Stateless (no handle). */
+int gitcap_preprocess(const uint8_t* frames_hwc_bgr, int nf, int H, int W, float* out_nchw, int crop, void* stream);
+
 /* Replaces: F.log_softmax(scores) + beam_scores, view(B, beams*V), torch.topk(2*beams)
  *                                                         src/models/model.py:557-565
  * logits: device fp32 [B*beams][ld]; beam_scores: device fp32 [B*beams]; outputs: device

@@ -694,6 +694,12 @@ int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launche
     return 0;
 }
 
+int gitcap_preprocess(const uint8_t* frames_hwc_bgr, int nf, int H, int W, float* out_nchw, int crop, void* stream) {
+    if (!frames_hwc_bgr || !out_nchw) return GITCAP_ERR_ARG;
+    hipError_t e = launch_preprocess(frames_hwc_bgr, out_nchw, nf, H, W, crop, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : (e == hipErrorInvalidValue ? GITCAP_ERR_ARG : GITCAP_ERR_HIP);
+}
+
 int gitcap_beam_topk(const float* logits, int ld, const float* beam_scores, int B, int beams, int V, int K,
                      float* out_scores, int32_t* out_idx, void* stream) {
     if (!logits || !beam_scores || !out_scores || !out_idx) return GITCAP_ERR_ARG;

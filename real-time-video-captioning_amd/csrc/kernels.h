@@ -96,3 +96,5 @@ hipError_t launch_gather_txt_rows(const bf16_t* src, bf16_t* dst, const int32_t*
 // top-K over (beam, vocab) of log_softmax(logits) + beam_scores, one block per batch element
 hipError_t launch_beam_topk(const float* logits, int ld, const float* beam_scores, int B, int beams, int V, int K,
                             float* out_scores, int* out_idx, hipStream_t s);
+// uint8 HWC BGR frames [nf][H][W][3] -> CLIP-normalised fp32 NCHW [nf][3][crop][crop] (bicubic resize + centre crop)
+hipError_t launch_preprocess(const unsigned char* in, float* out, int nf, int H, int W, int crop, hipStream_t s);

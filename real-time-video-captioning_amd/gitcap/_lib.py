@@ -26,6 +26,7 @@ SYMBOLS = {
     "gitcap_greedy": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gitcap_greedy_submit": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
     "gitcap_greedy_wait": (c_int, [c_void_p, c_int, c_void_p]),
+    "gitcap_preprocess": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gitcap_beam_topk": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gitcap_reorder_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gitcap_profile_enable": (c_int, [c_void_p, c_int]),
