@@ -60,6 +60,7 @@ class GitCaptioner(nn.Module):
     def __init__(self, cfg: Optional[GitCapConfig] = None, weights: Optional[Mapping[str, np.ndarray]] = None, *,
                  device: str | torch.device = "cuda:0", max_batch: int = 16, max_frames: Optional[int] = None,
                  max_text_len: int = 32, max_beams: int = 1, tokenizer=None, stop: str = "all_sep",
+                 weight_dtype: str = "bf16",
                  # constructor kwargs of the reference student (model.py:55-57); only the ids/vocab matter here
                  vocab_length: Optional[int] = None, cls_token_id: Optional[int] = None,
                  sep_token_id: Optional[int] = None, **_ignored_student_kwargs):
@@ -79,8 +80,11 @@ class GitCaptioner(nn.Module):
         self.tokenizer = tokenizer                      # attribute the reference's callers read (inference.py:43)
         self.cls_token_id, self.sep_token_id = cfg.cls_token_id, cfg.sep_token_id
         self.stop = stop
+        if weight_dtype not in ("bf16", "fp8_e4m3"):
+            raise ValueError("weight_dtype must be 'bf16' or 'fp8_e4m3'")
+        self.weight_dtype = weight_dtype
         self._kw = dict(max_batch=max_batch, max_frames=max_frames, max_text_len=max_text_len,
-                        max_beams=max_beams, stop=stop)
+                        max_beams=max_beams, stop=stop, weight_dtype=weight_dtype)
         self._dev = torch.device(device)
         self._handle = None
         self._weights: Optional[Dict[str, np.ndarray]] = None
@@ -160,6 +164,8 @@ class GitCaptioner(nn.Module):
             w = W.from_ms_state_dict(self.cfg, state_dict)
         else:
             raise KeyError("unrecognised checkpoint layout (expected canonical, HF-GIT or MS-GIT keys)")
+        if self.weight_dtype == "fp8_e4m3":      # BASELINE configs[4]: fp8 (e4m3) weight values, per-row 2^k scale
+            w = W.quantize_weights_fp8(w)
         self._upload(w)
         self._weights = w
         return self

@@ -118,3 +118,21 @@ def test_shard_range_partitions_exactly():
     assert shard_range(128, 3, 8) == (48, 64)            # configs[3]: 16 clips per GPU
     with pytest.raises(ValueError):
         shard_range(4, 4, 4)
+
+
+def test_fp8_weight_quantisation_is_exact_in_bf16_and_close():
+    import torch
+    cfg = git_tiny(2)
+    w = W.synthetic_weights(cfg, 0)
+    q = W.quantize_weights_fp8(w)
+    for k in w:
+        if not W.is_gemm_weight(k):
+            assert q[k] is w[k]
+            continue
+        t = torch.from_numpy(q[k])
+        assert torch.equal(t.bfloat16().float(), t), k                  # representable in bf16 exactly
+        rel = (t - torch.from_numpy(w[k])).abs() / torch.from_numpy(w[k]).abs().amax(dim=1, keepdim=True)
+        assert float(rel.max()) < 2 ** -4, k                            # e4m3: 3 mantissa bits
+        # idempotent: quantising again changes nothing
+    q2 = W.quantize_weights_fp8(q)
+    assert all(np.array_equal(q[k], q2[k]) for k in q)

@@ -255,3 +255,23 @@ def test_git_large_config_vs_oracle(captioner_cls):
     assert (lg - l_e).abs().max() < LOGIT_TOL_EMUL * 1.5, float((lg - l_e).abs().max())
     out = m.greedy_decode(fr, max_len=6, stop="never").cpu()
     _tokens_match_margin_gated(out, emul, fr)
+
+
+def test_fp8_weight_values_config4(captioner_cls):
+    """BASELINE configs[4] numerics: fp8 (e4m3, per-row power-of-two scale) weight values.  The oracle is
+    the fp32/bf16-emulating oracle on the SAME quantised weights ('fp8 weights dequantised in the oracle',
+    SURVEY.md par. 7)."""
+    from gitcap.weights import quantize_weights_fp8
+    cfg = git_tiny(2)
+    w = synthetic_weights(cfg, 0)
+    fr = make_frames(2, 2, cfg.image_size, 31)
+    m = captioner_cls(cfg, w, max_batch=2, max_text_len=8, max_beams=4, weight_dtype="fp8_e4m3")
+    emul = GitOracle(cfg, quantize_weights_fp8(w), emulate_bf16=True)
+    ids = torch.tensor([[101, 5, 9], [101, 77, 3]])
+    lg = m(fr, ids).cpu()
+    l_e, _ = emul.forward_output_logits(fr, ids)
+    assert (lg - l_e).abs().max() < LOGIT_TOL_EMUL
+    plain, _ = GitOracle(cfg, w, emulate_bf16=True).forward_output_logits(fr, ids)
+    assert (lg - plain).abs().max() > 3 * (lg - l_e).abs().max()      # the quantisation is really in effect
+    _tokens_match_margin_gated(m.greedy_decode(fr, max_len=6, stop="never").cpu(), emul, fr)
+    assert m.infer(fr, beam_size=4, max_steps=6)["predictions"].shape == (2, 6)
