@@ -159,7 +159,7 @@ int gitcap_profile_enable(gitcap_t* h, int enable);
 int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launches,
                         double* flops_total, double* bytes_total);
 
-/* Kernel-level test hooks (tests/test_kernels_gpu.py, scratch/gemm_bench.py): run ONE kernel on
+/* Kernel-level test hooks (tests/test_kernels_gpu.py, tools/gemm_bench.py): run ONE kernel on
  * caller-owned device buffers.  gemm: out[m][n] = sum_k A[m][k]*W[n][k] (+epilogue `epi` of
  * csrc/kernels.h: 0 bias->bf16, 1 bias+QuickGELU->bf16, 2 bias+GELU->bf16, 3 bias+resid->f32,
  * 4 bias->f32); A [M][K] bf16, W [N][K] bf16, M % 128 == 0; tile = 128 or 256. */

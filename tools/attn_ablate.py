@@ -10,5 +10,5 @@ def run(libpath, G, S, H, iters=20):
     for _ in range(iters): call()
     e1.record(); torch.cuda.synchronize()
     return round(e0.elapsed_time(e1) / iters * 1e3, 1)
-libs = {'full': 'real-time-video-captioning_amd/gitcap/libgitcap.so', 'noexp': 'scratch/libgitcap_v1.so', 'noPV': 'scratch/libgitcap_v2.so', 'noQK': 'scratch/libgitcap_v3.so', 'nobarrier': 'scratch/libgitcap_v4.so'}
+libs = {'full': 'real-time-video-captioning_amd/gitcap/libgitcap.so', 'noexp': 'tools/libgitcap_v1.so', 'noPV': 'tools/libgitcap_v2.so', 'noQK': 'tools/libgitcap_v3.so', 'nobarrier': 'tools/libgitcap_v4.so'}
 print({k: run(v, 16, 1182, 12) for k, v in libs.items()})

@@ -14,6 +14,6 @@ def bench(libpath, M, N, K, epi, tile=256, iters=20):
     for _ in range(iters): call()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-libs = {'full': 'real-time-video-captioning_amd/gitcap/libgitcap.so', 'noDMA': 'scratch/libgitcap_A.so', 'noLDSread': 'scratch/libgitcap_B.so', 'neither': 'scratch/libgitcap_C.so'}
+libs = {'full': 'real-time-video-captioning_amd/gitcap/libgitcap.so', 'noDMA': 'tools/libgitcap_A.so', 'noLDSread': 'tools/libgitcap_B.so', 'neither': 'tools/libgitcap_C.so'}
 for (N, K, epi) in [(768, 768, 0), (768, 3072, 0), (3072, 768, 0)]:
     print(N, K, epi, {k: round(bench(v, 18944, N, K, epi), 1) for k, v in libs.items()})
