@@ -20,7 +20,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "real-time-video-captioning_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
@@ -28,7 +28,7 @@ for p in (ROOT, os.path.join(ROOT, "real-time-video-captioning_amd")):
 import numpy as np      # noqa: E402
 import torch            # noqa: E402
 
-CLIPS_PER_GPU, FRAMES, TOKENS = 16, 6, 20
+CLIPS_PER_GPU, FRAMES, TOKENS = int(os.environ.get("BENCH_B", "16")), 6, 20
 GFLOP_PER_CAPTION = 341.5          # SURVEY.md par. 8(d): GIT-base F=6 T=20, KV-cached, encoder once
 MFMA_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
@@ -79,8 +79,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter: 1-rank rehearsal of the N>1 path
-    if use_dist:
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
@@ -96,10 +95,10 @@ def main():
     # rank r holds clips [r*16, (r+1)*16) of the global batch; inputs are resident in HBM
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     frames = torch.randn(CLIPS_PER_GPU, FRAMES, 3, cfg.image_size, cfg.image_size, generator=g).to(dev)
-    gathered = torch.empty((world * CLIPS_PER_GPU, TOKENS + 1), dtype=torch.int64, device=dev) if use_dist else None
+    gathered = torch.empty((world * CLIPS_PER_GPU, TOKENS + 1), dtype=torch.int64, device=dev) if world > 1 else None
 
     def finish(ids):
-        if use_dist:
+        if world > 1:
             dist.all_gather_into_tensor(gathered, ids)    # rank-major: output row i is global clip i
             return gathered
         return ids
@@ -108,7 +107,7 @@ def main():
         return finish(model.greedy_decode(frames, max_len=TOKENS, stop="never"))
 
     def fence():
-        if use_dist:
+        if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -142,7 +141,7 @@ def main():
     elapsed = time.perf_counter() - t0
     lat = sorted(ev_sub[i].elapsed_time(ev_done[i]) for i in range(args.steps))   # submit -> ids ready, per batch
     p50 = lat[len(lat) // 2]
-    if use_dist:
+    if world > 1:
         t = torch.tensor([elapsed, p50], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, p50 = float(t[0]), float(t[1])
@@ -211,12 +210,12 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: batch=16 6-frame 224x224 clips per GPU, GIT-base "
                                    "(ViT-B/16 + 6-layer decoder), 20-token greedy, EOS disabled",
                        "clips_per_gpu": CLIPS_PER_GPU, "frames": FRAMES, "tokens": TOKENS, "global_batch": world * CLIPS_PER_GPU,
-                       "parallelism": f"dp{world}", "batches_in_flight": 1 if args.serial else args.inflight, "collective": "all_gather(int64[16,21]) per step" if use_dist else "none"},
+                       "parallelism": f"dp{world}", "batches_in_flight": 1 if args.serial else args.inflight, "collective": "all_gather(int64[16,21]) per step" if world > 1 else "none"},
             "caption_mfma_frac": round(value / world * GFLOP_PER_CAPTION / 1e3 / MFMA_PEAK_TFLOPS, 4),
             "serial": serial, "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown,
         }
         print(json.dumps(line), flush=True)
-    if use_dist:
+    if world > 1:
         dist.destroy_process_group()
 
 
