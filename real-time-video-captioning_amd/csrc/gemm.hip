@@ -135,7 +135,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
 
 template <int EPI>
 hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    static bool attr_done[64] = {false};            // per device: the attribute belongs to the device's code object
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_done[dev_ & 63];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

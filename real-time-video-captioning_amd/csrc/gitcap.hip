@@ -134,6 +134,18 @@ void select_slot(gitcap* h, int i) {
             return fail(h, GITCAP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
     } while (0)
 
+// Makes the handle's device current for the duration of an entry point and restores the caller's.
+struct DeviceGuard {
+    int prev = -1; bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+        if (prev == dev) prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define GUARD(h) DeviceGuard guard_((h)->device); if (!guard_.ok) return fail(h, GITCAP_ERR_HIP, "cannot select the handle's device")
+
 struct ProfScope {
     gitcap* h; hipStream_t s; gitcap::ProfRec* r = nullptr;
     ProfScope(gitcap* h_, int cls, hipStream_t s_, double flops, double bytes) : h(h_), s(s_) {
@@ -463,11 +475,11 @@ int gitcap_load_tensor(gitcap_t* h, const char* name, const float* data, const i
     if (!h || !name || !data || !shape) return fail(h, GITCAP_ERR_ARG, "load_tensor: null argument");
     auto it = h->w.find(name);
     if (it == h->w.end()) return fail(h, GITCAP_ERR_ARG, std::string("load_tensor: unknown tensor '") + name + "'");
+    GUARD(h);
     DevTensor& t = it->second;
     if ((int)t.shape.size() != rank) return fail(h, GITCAP_ERR_ARG, std::string("load_tensor: rank mismatch for ") + name);
     for (int i = 0; i < rank; ++i)
         if (t.shape[i] != shape[i]) return fail(h, GITCAP_ERR_ARG, std::string("load_tensor: shape mismatch for ") + name);
-    HIP_OK(h, hipSetDevice(h->device));
     const int64_t rows = rank == 2 ? shape[0] : 1, cols = rank == 2 ? shape[1] : shape[0];
     if (t.p) { (void)hipFree(t.p); t.p = nullptr; }
     if (t.bf16) {
@@ -490,6 +502,7 @@ int gitcap_load_tensor(gitcap_t* h, const char* name, const float* data, const i
 
 int gitcap_finalize_weights(gitcap_t* h) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "finalize: null handle");
+    GUARD(h);
     for (auto& kv : h->w)
         if (!kv.second.loaded) return fail(h, GITCAP_ERR_STATE, "finalize: tensor '" + kv.first + "' was never loaded");
     auto F = [&](const std::string& n) { return (const float*)h->w[n].p; };
@@ -524,6 +537,7 @@ int gitcap_finalize_weights(gitcap_t* h) {
 
 int gitcap_encode(gitcap_t* h, const float* frames, int B, int F, float* visual_out, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "encode: null handle");
+    GUARD(h);
     select_slot(h, 0);
     return encode_impl(h, frames, B, F, visual_out, (hipStream_t)stream);
 }
@@ -574,6 +588,7 @@ static int encode_impl(gitcap* h, const float* frames, int B, int F, float* visu
 
 int gitcap_set_visual(gitcap_t* h, const float* visual, int B, int S_img, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "set_visual: null handle");
+    GUARD(h);
     if (!h->finalized) return fail(h, GITCAP_ERR_STATE, "weights not finalized");
     select_slot(h, 0);
     if (!visual || B <= 0 || S_img <= 0) return fail(h, GITCAP_ERR_ARG, "set_visual: bad arguments");
@@ -588,6 +603,7 @@ int gitcap_set_visual(gitcap_t* h, const float* visual, int B, int S_img, void* 
 int gitcap_text_forward(gitcap_t* h, const int64_t* ids, int ld_ids, int rows, int beams, int t0, int T,
                         float* logits_out, int all_positions, int64_t* argmax_out, int ld_argmax, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "text_forward: null handle");
+    GUARD(h);
     select_slot(h, 0);
     return text_forward(h, ids, ld_ids, rows, beams, t0, T, logits_out, all_positions, argmax_out, ld_argmax, nullptr, 0,
                         (hipStream_t)stream);
@@ -618,6 +634,7 @@ static int greedy_check(gitcap* h, int max_len, int stop, const int64_t* ids_out
 int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, int stop, int64_t* ids_out,
                   int32_t* steps_out, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "greedy: null handle");
+    GUARD(h);
     int rc = greedy_check(h, max_len, stop, ids_out);
     if (rc) return rc;
     select_slot(h, 0);
@@ -628,6 +645,7 @@ int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, i
 int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max_len, int stop, int64_t* ids_out,
                          int32_t* steps_out, void* stream, int* ticket) {
     if (!h || !ticket) return fail(h, GITCAP_ERR_ARG, "greedy_submit: null argument");
+    GUARD(h);
     int rc = greedy_check(h, max_len, stop, ids_out);
     if (rc) return rc;
     const int slot = h->next_ticket % gitcap::NSLOT;
@@ -651,6 +669,7 @@ int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max
 
 int gitcap_greedy_wait(gitcap_t* h, int ticket, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "greedy_wait: null handle");
+    GUARD(h);
     if (ticket < 0 || ticket >= h->next_ticket || ticket < h->next_ticket - gitcap::NSLOT)
         return fail(h, GITCAP_ERR_ARG, "greedy_wait: ticket is not one of the submissions in flight");
     HIP_OK(h, hipStreamWaitEvent((hipStream_t)stream, h->slots[ticket % gitcap::NSLOT].ev_dec, 0));
@@ -659,6 +678,7 @@ int gitcap_greedy_wait(gitcap_t* h, int ticket, void* stream) {
 
 int gitcap_reorder_rows(gitcap_t* h, const int32_t* src_rows, int rows, int t_len, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "reorder_rows: null handle");
+    GUARD(h);
     if (!src_rows || rows <= 0 || rows > h->R || t_len < 0 || t_len > h->Tmax)
         return fail(h, GITCAP_ERR_ARG, "reorder_rows: bad arguments");
     hipStream_t s = (hipStream_t)stream;

@@ -189,6 +189,8 @@ class GitCaptioner(nn.Module):
             x = x.unsqueeze(1)
         if x.dim() != 5 or x.shape[2] != 3 or x.shape[3] != self.cfg.image_size or x.shape[4] != self.cfg.image_size:
             raise ValueError(f"expected frames [B,F,3,{self.cfg.image_size},{self.cfg.image_size}], got {tuple(x.shape)}")
+        if x.shape[0] == 0:
+            raise ValueError("empty batch")
         if x.shape[1] > self.max_frames:
             raise ValueError(f"{x.shape[1]} frames per clip > max_frames={self.max_frames}")
         x = x.to(device=self._dev, dtype=torch.float32).contiguous()

@@ -275,3 +275,31 @@ def test_fp8_weight_values_config4(captioner_cls):
     assert (lg - plain).abs().max() > 3 * (lg - l_e).abs().max()      # the quantisation is really in effect
     _tokens_match_margin_gated(m.greedy_decode(fr, max_len=6, stop="never").cpu(), emul, fr)
     assert m.infer(fr, beam_size=4, max_steps=6)["predictions"].shape == (2, 6)
+
+
+def test_more_edge_inputs(captioner_cls):
+    cfg = git_tiny(2)
+    w = synthetic_weights(cfg, 0)
+    m = captioner_cls(cfg, w, max_batch=4, max_text_len=8)
+    fr = make_frames(3, 2, cfg.image_size, 12)
+    want = m.greedy_decode(fr, max_len=8, stop="never").cpu()                 # max_len == max_text_len boundary
+    assert want.shape == (3, 9)
+    # non-contiguous view, float64 and an odd storage offset all take the same path
+    big = torch.zeros(3, 2, 3, cfg.image_size, cfg.image_size + 3, dtype=torch.float64)
+    big[..., 1:cfg.image_size + 1] = fr.double()
+    view = big[..., 1:cfg.image_size + 1]
+    assert not view.is_contiguous()
+    assert torch.equal(m.greedy_decode(view, max_len=8, stop="never").cpu(), want)
+    with pytest.raises(ValueError):
+        m.greedy_decode(torch.zeros(0, 2, 3, cfg.image_size, cfg.image_size), max_len=4)     # empty batch
+    with pytest.raises(ValueError):
+        m.greedy_decode(torch.zeros(1, 3, 3, cfg.image_size, cfg.image_size), max_len=4)     # F > max_frames
+    # token ids outside the vocabulary are clamped, never read out of bounds
+    _, mem = m.forward_image_enc(fr)
+    y = torch.tensor([[101, 10 ** 6, -5]] * 3)
+    assert torch.isfinite(m.forward_decoder(y, mem)).all()
+    # two handles side by side do not share state
+    m2 = captioner_cls(cfg, synthetic_weights(cfg, 1), max_batch=4, max_text_len=8)
+    a2 = m2.greedy_decode(fr, max_len=8, stop="never").cpu()
+    assert torch.equal(m.greedy_decode(fr, max_len=8, stop="never").cpu(), want)
+    assert not torch.equal(a2, want)
