@@ -67,7 +67,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--serial", action="store_true", help="one batch at a time (no cross-batch pipelining)")
-    ap.add_argument("--inflight", type=int, default=4, choices=(2, 3, 4), help="batches in flight when pipelined")
+    ap.add_argument("--inflight", type=int, default=4, choices=(2, 3, 4), help="submissions in flight when pipelined")
+    ap.add_argument("--coalesce", type=int, default=1, choices=(1, 2, 4),
+                    help="dynamic batching: run this many consecutive 16-clip batches as one pass")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,7 +93,7 @@ def main():
 
     cfg = git_base(FRAMES)
     weights = synthetic_weights(cfg, seed=0)
-    model = GitCaptioner(cfg, weights, device=dev, max_batch=CLIPS_PER_GPU, max_frames=FRAMES,
+    model = GitCaptioner(cfg, weights, device=dev, max_batch=CLIPS_PER_GPU * args.coalesce, max_frames=FRAMES,
                          max_text_len=TOKENS, stop="never")
     # rank r holds clips [r*16, (r+1)*16) of the global batch; inputs are resident in HBM
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -130,8 +132,8 @@ def main():
         pending = []
         for i in range(args.steps):
             ev_sub[i].record()
-            pending.append((i, model.greedy_decode_async(frames, max_len=TOKENS, stop="never")))
-            if len(pending) == args.inflight:
+            pending.append((i, model.greedy_decode_async(frames, max_len=TOKENS, stop="never", coalesce=args.coalesce)))
+            if len(pending) == args.inflight * args.coalesce:
                 j, fut = pending.pop(0)
                 out = finish(fut.result())
                 ev_done[j].record()
@@ -211,7 +213,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: batch=16 6-frame 224x224 clips per GPU, GIT-base "
                                    "(ViT-B/16 + 6-layer decoder), 20-token greedy, EOS disabled",
                        "clips_per_gpu": CLIPS_PER_GPU, "frames": FRAMES, "tokens": TOKENS, "global_batch": world * CLIPS_PER_GPU,
-                       "parallelism": f"dp{world}", "batches_in_flight": 1 if args.serial else args.inflight, "collective": "all_gather(int64[16,21]) per step" if use_dist else "none"},
+                       "parallelism": f"dp{world}", "batches_in_flight": 1 if args.serial else args.inflight * args.coalesce, "coalesce": args.coalesce, "collective": "all_gather(int64[16,21]) per step" if use_dist else "none"},
             "caption_mfma_frac": round(value / world * GFLOP_PER_CAPTION / 1e3 / MFMA_PEAK_TFLOPS, 4),
             "serial": serial, "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown,
         }

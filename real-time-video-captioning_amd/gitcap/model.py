@@ -31,24 +31,44 @@ from . import weights as W
 STOP_NEVER, STOP_ALL_SEP = 0, 1
 
 
-class CaptionFuture:
-    """Handle of one gitcap_greedy_submit; keeps the device buffers alive until result()."""
+class _Submission:
+    """One gitcap_greedy_submit (possibly several coalesced caller batches); keeps its buffers alive."""
 
-    def __init__(self, model, ticket, ids, steps, frames, mode, out_device):
-        self._m, self._ticket, self._ids, self._steps = model, ticket, ids, steps
-        self._frames, self._mode, self._out_device = frames, mode, out_device
-        self._done = False
+    def __init__(self, ticket, ids, steps, frames, coalesced):
+        self.ticket, self.ids, self.steps, self.frames, self.coalesced = ticket, ids, steps, frames, coalesced
+        self.waited = False
+
+
+class CaptionFuture:
+    """Result handle of greedy_decode_async."""
+
+    def __init__(self, model, frames, mode, max_len, out_device):
+        self._m, self._frames, self._mode, self._max_len, self._out_device = model, frames, mode, max_len, out_device
+        self._sub, self._r0, self._r1 = None, 0, 0
+
+    def _attach(self, sub, r0, r1):
+        self._sub, self._r0, self._r1 = sub, r0, r1
+        self._frames = None                      # the submission holds the (concatenated) frames now
 
     def result(self) -> torch.Tensor:
         m = self._m
-        if not self._done:
+        if self._sub is None:                    # still waiting for partners to coalesce with: run now
+            m._flush_pending()
+        sub = self._sub
+        if not sub.waited:
             with torch.cuda.device(m._dev):
-                m._call("gitcap_greedy_wait", self._ticket, m._stream())
-            self._done = True
-            self._frames = None
-        ids = self._ids
+                m._call("gitcap_greedy_wait", sub.ticket, m._stream())
+            sub.waited = True
+            sub.frames = None
+        ids = sub.ids[self._r0:self._r1]
         if self._mode == STOP_ALL_SEP:
-            ids = ids[:, :1 + int(self._steps.item())]
+            if sub.coalesced:                    # reference rule over THIS caller batch (model.py:184)
+                all_sep = (ids[:, 1:] == m.sep_token_id).all(dim=0)
+                nz = torch.nonzero(all_sep)
+                n = int(nz[0].item()) + 1 if nz.numel() else self._max_len
+            else:
+                n = int(sub.steps.item())
+            ids = ids[:, :1 + n]
         return ids.to(self._out_device) if self._out_device != ids.device else ids
 
 
@@ -89,6 +109,7 @@ class GitCaptioner(nn.Module):
         self._handle = None
         self._weights: Optional[Dict[str, np.ndarray]] = None
         self._last_memory = None
+        self._pending, self._pending_key = [], None
         self._lib = _lib.load()                         # raises if libgitcap.so is missing
         self._create()
         if weights is not None:
@@ -283,28 +304,58 @@ class GitCaptioner(nn.Module):
     generate = greedy_decode      # the name BASELINE.json's north_star uses for this entry point
 
     @torch.no_grad()
-    def greedy_decode_async(self, src: torch.Tensor, max_len: int = 10, stop: Optional[str] = None) -> "CaptionFuture":
+    def greedy_decode_async(self, src: torch.Tensor, max_len: int = 10, stop: Optional[str] = None,
+                            coalesce: int = 1) -> "CaptionFuture":
         """Pipelined greedy_decode for a stream of batches: returns immediately with a future; up to
-        FOUR batches may be in flight, so one batch's image pass (MFMA bound) overlaps the token
+        FOUR submissions may be in flight, so one batch's image pass (MFMA bound) overlaps the token
         loops (latency bound) of the batches before it on the handle's internal HIP streams.  Call
-        ``.result()`` (in submission order) to make the current stream wait and get the ids."""
+        ``.result()`` (in submission order) to make the current stream wait and get the ids.
+
+        ``coalesce=k`` (dynamic batching): k consecutive calls with the same shape are concatenated and
+        run as ONE pass of k*B clips (the per-clip results are bitwise the same: the kernels are batch
+        invariant); a ``result()`` on a batch that is still waiting for partners flushes it.  Needs
+        max_batch >= k*B."""
         stop = stop or self.stop
         mode = {"all_sep": STOP_ALL_SEP, "never": STOP_NEVER}[stop]
         if max_len > self.max_text_len:
             raise ValueError(f"max_len {max_len} > max_text_len={self.max_text_len} the handle was created for")
         fr = self._frames(src)
-        B, F = fr.shape[:2]
-        if B > self.max_batch:
-            raise ValueError(f"batch {B} > max_batch={self.max_batch}")
+        B = fr.shape[0]
+        if B * max(1, coalesce) > self.max_batch:
+            raise ValueError(f"batch {B} x coalesce {coalesce} > max_batch={self.max_batch}")
+        fut = CaptionFuture(self, fr, mode, max_len, src.device)
+        key = (tuple(fr.shape), max_len, mode)
+        if self._pending and self._pending_key != key:
+            self._flush_pending()
+        self._pending.append(fut)
+        self._pending_key = key
+        if len(self._pending) >= max(1, coalesce):
+            self._flush_pending()
+        return fut
+
+    def _flush_pending(self):
+        """Submit the waiting batches as one pass and hand each future its row range."""
+        group, self._pending = self._pending, []
+        if not group:
+            return
+        frames = group[0]._frames if len(group) == 1 else torch.cat([f._frames for f in group], 0)
+        B, F = frames.shape[:2]
+        max_len, mode = group[0]._max_len, group[0]._mode
         with torch.cuda.device(self._dev):
             ids = torch.empty((B, max_len + 1), dtype=torch.int64, device=self._dev)
             steps = torch.zeros((1,), dtype=torch.int32, device=self._dev)
             ticket = ctypes.c_int(-1)
-            self._call("gitcap_greedy_submit", ctypes.c_void_p(fr.data_ptr()), B, F, max_len, mode,
+            self._call("gitcap_greedy_submit", ctypes.c_void_p(frames.data_ptr()), B, F, max_len,
+                       STOP_NEVER if len(group) > 1 else mode,       # the stop rule is per caller batch: applied in result()
                        ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(steps.data_ptr()), self._stream(),
                        ctypes.byref(ticket))
         self._last_memory = None
-        return CaptionFuture(self, ticket.value, ids, steps, fr, mode, src.device)
+        shared = _Submission(ticket.value, ids, steps, frames, len(group) > 1)
+        r0 = 0
+        for f in group:
+            n = f._frames.shape[0]
+            f._attach(shared, r0, r0 + n)
+            r0 += n
 
     @torch.no_grad()
     def step_logits(self, ids_last: torch.Tensor, t: int, beams: int = 1) -> torch.Tensor:

@@ -223,6 +223,13 @@ def test_pipelined_submit_matches_synchronous(captioner_cls):
     for a, b in zip(want, got):
         assert torch.equal(a, b)
     assert torch.equal(m.greedy_decode(batches[0], max_len=8, stop="never"), want[0])   # sync path still fine afterwards
+    # dynamic batching: pairs of submissions run as one 8-row pass; a lone tail batch flushes on result()
+    m8 = captioner_cls(cfg, synthetic_weights(cfg, 0), max_batch=8, max_text_len=8)
+    futs = [m8.greedy_decode_async(b, max_len=8, stop="never", coalesce=2) for b in batches]
+    for a, f in zip(want, futs):
+        assert torch.equal(a, f.result())
+    with pytest.raises(ValueError):
+        m.greedy_decode_async(batches[0], max_len=8, coalesce=2)          # 2 x 4 rows > max_batch 4
 
 
 def test_pickle_roundtrip(captioner_cls):
