@@ -129,6 +129,19 @@ int gitcap_preprocess(const uint8_t* frames_hwc_bgr, int nf, int H, int W, float
 int gitcap_beam_topk(const float* logits, int ld, const float* beam_scores, int B, int beams, int V, int K,
                      float* out_scores, int32_t* out_idx, void* stream);
 
+/* Replaces: GenerativeImageTextModel.infer + GeneratorWithBeamSearchV2.search
+ *                                                         src/models/model.py:426-462, :479-678
+ * (num_keep_best = 1, do_sample = False: the way GenerativeImageTextTeacher.forward drives it, :768).
+ * The whole search runs on the device with no host round trip: per step decoder forward, beam top-k
+ * (log-softmax + beam scores, :557-565), hypothesis/beam bookkeeping (:573-621) and the KV reorder the
+ * reference leaves commented out (:623-634).  decoded_out: device int64 [B][max_steps], CLS-prefixed best
+ * hypothesis padded with EOS (:671-675); logprobs_out: device fp32 [B] (:665).  The reference's early
+ * `break` when every sentence is done (:640) is not needed for correctness (done sentences ignore their
+ * candidates) and is not taken: all max_steps-1 steps are enqueued. */
+int gitcap_beam_search(gitcap_t* h, const float* frames, int B, int F, int beams, int max_steps,
+                       float length_penalty, int per_node_beam_size,
+                       int64_t* decoded_out, float* logprobs_out, void* stream);
+
 /* Pipelined form of gitcap_greedy for a stream of batches (no reference counterpart: the reference
  * processes one clip at a time, src/models/model.py:765).  submit enqueues the image pass on the
  * handle's encoder stream and the text loop on its decoder stream, ordered after the work already

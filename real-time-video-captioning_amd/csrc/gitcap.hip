@@ -64,6 +64,10 @@ struct gitcap {
     int* amax_idx = nullptr;
     bf16_t *xsb = nullptr, *cs = nullptr, *fs = nullptr, *kv_txt = nullptr, *kv_txt2 = nullptr;
     int32_t* sep_cnt = nullptr;
+    BeamBuffers beam{};                 // device-resident beam-search state (gitcap_beam_search)
+    float* beam_logits = nullptr;       // [R][V]
+    float* cand_scores = nullptr;       // [B][16]
+    int* cand_idx = nullptr;
 
     // resolved weights
     const bf16_t *patch_w = nullptr, *vproj_w = nullptr, *head_w = nullptr;
@@ -422,6 +426,21 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
         rc = rc ? rc : ws_alloc(h, &sl.kv_txt, (size_t)c.dec_layers * h->R * h->Tmax * 3 * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.kv_txt2, (size_t)c.dec_layers * h->R * h->Tmax * 3 * h->D);
     }
+    {   // beam-search state (slot-independent: the synchronous beam path uses slot 0)
+        const size_t R = h->R, T = (size_t)h->Tmax + 1, Bm = c.max_batch;
+        rc = rc ? rc : ws_alloc(h, &h->beam.ids0, R * T);
+        rc = rc ? rc : ws_alloc(h, &h->beam.ids1, R * T);
+        rc = rc ? rc : ws_alloc(h, &h->beam.words, R);
+        rc = rc ? rc : ws_alloc(h, &h->beam.hyp_ids, Bm * T);
+        rc = rc ? rc : ws_alloc(h, &h->beam.beam_scores, R);
+        rc = rc ? rc : ws_alloc(h, &h->beam.hyp_score, Bm);
+        rc = rc ? rc : ws_alloc(h, &h->beam.src_rows, R);
+        rc = rc ? rc : ws_alloc(h, &h->beam.done, Bm);
+        rc = rc ? rc : ws_alloc(h, &h->beam.hyp_len, Bm);
+        rc = rc ? rc : ws_alloc(h, &h->beam_logits, R * (size_t)h->V);
+        rc = rc ? rc : ws_alloc(h, &h->cand_scores, Bm * 16);
+        rc = rc ? rc : ws_alloc(h, &h->cand_idx, Bm * 16);
+    }
     if (!rc) {   // select slot 0
         gitcap::Slot& n = h->slots[0];
         h->sep_cnt = n.sep_cnt; h->xs = n.xs; h->slabs = n.slabs; h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
@@ -673,6 +692,44 @@ int gitcap_greedy_wait(gitcap_t* h, int ticket, void* stream) {
     if (ticket < 0 || ticket >= h->next_ticket || ticket < h->next_ticket - gitcap::NSLOT)
         return fail(h, GITCAP_ERR_ARG, "greedy_wait: ticket is not one of the submissions in flight");
     HIP_OK(h, hipStreamWaitEvent((hipStream_t)stream, h->slots[ticket % gitcap::NSLOT].ev_dec, 0));
+    return 0;
+}
+
+int gitcap_beam_search(gitcap_t* h, const float* frames, int B, int F, int beams, int max_steps, float length_penalty,
+                       int per_node_beam_size, int64_t* decoded_out, float* logprobs_out, void* stream) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "beam_search: null handle");
+    GUARD(h);
+    if (!decoded_out || !logprobs_out || beams < 1 || per_node_beam_size < 1) return fail(h, GITCAP_ERR_ARG, "beam_search: bad arguments");
+    if (beams > h->c.max_beams || beams > 16 || beams * per_node_beam_size > 16)
+        return fail(h, GITCAP_ERR_ARG, "beam_search: beams exceed max_beams / 16 candidates");
+    if (max_steps < 2 || max_steps > h->Tmax) return fail(h, GITCAP_ERR_ARG, "beam_search: max_steps outside [2, max_text_len]");
+    hipStream_t s = (hipStream_t)stream;
+    select_slot(h, 0);
+    int rc = encode_impl(h, frames, B, F, nullptr, s);
+    if (rc) return rc;
+    const int rows = B * beams, K = beams * per_node_beam_size, V = h->c.vocab_size, L = max_steps;
+    HIP_OK(h, launch_beam_init(h->beam, B, beams, L, h->c.cls_token_id, s));
+    // while cur_len < max_length (model.py:518): the token at position cur_len-1 is decoded, candidates for
+    // position cur_len are ranked, bookkept and the text K/V rows follow their beams -- no host round trip
+    for (int cur_len = 1, cur = 0; cur_len < L; ++cur_len, cur ^= 1) {
+        const int t = cur_len - 1;
+        if (t > 0) HIP_OK(h, [&]() -> hipError_t {                          // rows continue beam src_rows[r]
+            const size_t layer = (size_t)h->R * h->Tmax * 3 * h->D;
+            for (int l = 0; l < h->c.dec_layers; ++l) {
+                hipError_t e = launch_gather_txt_rows(h->kv_txt + l * layer, h->kv_txt2 + l * layer, h->beam.src_rows, rows, t,
+                                                      h->Tmax, 3 * h->D, s);
+                if (e != hipSuccess) return e;
+            }
+            std::swap(h->kv_txt, h->kv_txt2);
+            return hipSuccess;
+        }());
+        rc = text_forward(h, h->beam.words, 1, rows, beams, t, 1, h->beam_logits, 0, nullptr, 0, nullptr, 0, s);
+        if (rc) return rc;
+        HIP_OK(h, launch_beam_topk(h->beam_logits, V, h->beam.beam_scores, B, beams, V, K, h->cand_scores, h->cand_idx, s));
+        HIP_OK(h, launch_beam_step(h->beam, h->cand_scores, h->cand_idx, B, beams, K, V, cur_len, L, h->c.sep_token_id,
+                                   length_penalty, cur, s));
+    }
+    HIP_OK(h, launch_beam_finish(h->beam, B, L, h->c.sep_token_id, decoded_out, logprobs_out, s));
     return 0;
 }
 

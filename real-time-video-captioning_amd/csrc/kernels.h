@@ -98,3 +98,13 @@ hipError_t launch_beam_topk(const float* logits, int ld, const float* beam_score
                             float* out_scores, int* out_idx, hipStream_t s);
 // uint8 HWC BGR frames [nf][H][W][3] -> CLIP-normalised fp32 NCHW [nf][3][crop][crop] (bicubic resize + centre crop)
 hipError_t launch_preprocess(const unsigned char* in, float* out, int nf, int H, int W, int crop, hipStream_t s);
+// device-resident beam search state + one bookkeeping step per decoder step (rowops.hip)
+struct BeamBuffers {
+    int64_t *ids0, *ids1, *words, *hyp_ids;
+    float *beam_scores, *hyp_score;
+    int32_t *src_rows, *done, *hyp_len;
+};
+hipError_t launch_beam_init(const BeamBuffers& bb, int B, int beams, int max_len, int cls, hipStream_t s);
+hipError_t launch_beam_step(const BeamBuffers& bb, const float* cand_scores, const int* cand_idx, int B, int beams, int K,
+                            int V, int cur_len, int max_len, int eos, float length_penalty, int cur, hipStream_t s);
+hipError_t launch_beam_finish(const BeamBuffers& bb, int B, int max_len, int eos, int64_t* decoded, float* logprobs, hipStream_t s);

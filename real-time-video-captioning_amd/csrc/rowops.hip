@@ -331,6 +331,94 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict_
     }
 }
 
+// ---- device-side beam bookkeeping: one step of GeneratorWithBeamSearchV2.search (model.py:573-621) -----
+// One block per batch element; thread 0 walks the <= 16 sorted candidates exactly like the reference's
+// Python loop (finished hypotheses kept n_best = 1: score = sum_logprob / len^length_penalty, :503, :592-594;
+// is_done test :576), then the block copies the surviving prefixes into the next id buffer (:620-621).
+struct BeamState {
+    int64_t* ids[2];          // [B*beams][max_len] prefixes, double buffered
+    float* beam_scores;       // [B*beams]
+    int64_t* words;           // [B*beams] token chosen for the next position (input of the next decoder step)
+    int32_t* src_rows;        // [B*beams] row each new beam continues (for the KV reorder)
+    int32_t* done;            // [B]
+    int32_t* hyp_len;         // [B] 0 = no finished hypothesis yet
+    float* hyp_score;         // [B]
+    int64_t* hyp_ids;         // [B][max_len]
+};
+__global__ __launch_bounds__(64) void beam_step_kernel(BeamState st, const float* __restrict__ cand_scores,
+                                                       const int* __restrict__ cand_idx, int beams, int K, int V,
+                                                       int cur_len, int max_len, int eos, float length_penalty, int cur) {
+    __shared__ int s_src[16];
+    __shared__ long long s_word[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t* ids_old = st.ids[cur];
+    int64_t* ids_new = st.ids[cur ^ 1];
+    if (tid == 0) {
+        const float* cs = cand_scores + (size_t)b * K;
+        const int* ci = cand_idx + (size_t)b * K;
+        bool done = st.done[b] != 0;
+        if (!done && st.hyp_len[b] > 0)                                   // BeamHypotheses.is_done(best_sum_logprobs)
+            done = st.hyp_score[b] >= cs[0] / powf((float)(max_len - 1), length_penalty);
+        int kept = 0;
+        if (!done) {
+            for (int c = 0; c < K && kept < beams; ++c) {
+                const int beam_id = ci[c] / V, word = ci[c] - beam_id * V;
+                if (word == eos || cur_len + 1 == max_len) {              // finished hypothesis: ids[:cur_len]
+                    const float score = cs[c] / powf((float)cur_len, length_penalty);
+                    if (st.hyp_len[b] == 0 || score > st.hyp_score[b]) {
+                        st.hyp_score[b] = score;
+                        st.hyp_len[b] = cur_len;
+                        const int64_t* srow = ids_old + (size_t)(b * beams + beam_id) * max_len;
+                        for (int t = 0; t < cur_len; ++t) st.hyp_ids[(size_t)b * max_len + t] = srow[t];
+                    }
+                } else {
+                    s_src[kept] = b * beams + beam_id;
+                    s_word[kept] = word;
+                    st.beam_scores[b * beams + kept] = cs[c];
+                    ++kept;
+                }
+            }
+        }
+        if (kept < beams) {                                               // done, or the last step: pad (0, eos, row 0)
+            for (int j = 0; j < beams; ++j) {
+                s_src[j] = 0; s_word[j] = eos;
+                st.beam_scores[b * beams + j] = 0.f;
+            }
+        }
+        st.done[b] = done ? 1 : 0;
+    }
+    __syncthreads();
+    for (int j = 0; j < beams; ++j) {
+        const int r = b * beams + j, src = s_src[j];
+        for (int t = tid; t < cur_len; t += 64) ids_new[(size_t)r * max_len + t] = ids_old[(size_t)src * max_len + t];
+        if (tid == 0) {
+            ids_new[(size_t)r * max_len + cur_len] = s_word[j];
+            st.words[r] = s_word[j];
+            st.src_rows[r] = src;
+        }
+    }
+}
+
+// decoded[b] = best hypothesis + EOS padding (model.py:653-678, num_keep_best = 1)
+__global__ void beam_finish_kernel(BeamState st, int max_len, int eos, int64_t* __restrict__ decoded, float* __restrict__ logprobs) {
+    const int b = blockIdx.x;
+    const int n = st.hyp_len[b];
+    for (int t = threadIdx.x; t < max_len; t += blockDim.x)
+        decoded[(size_t)b * max_len + t] = t < n ? st.hyp_ids[(size_t)b * max_len + t] : eos;
+    if (threadIdx.x == 0) logprobs[b] = n > 0 ? st.hyp_score[b] : -1e5f;
+}
+
+__global__ void beam_init_kernel(BeamState st, int B, int beams, int max_len, int cls) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < B * beams) {
+        st.ids[0][(size_t)r * max_len] = cls;
+        st.words[r] = cls;
+        st.beam_scores[r] = (r % beams == 0) ? 0.f : -1e9f;                 // model.py:508-509
+        st.src_rows[r] = r;
+    }
+    if (r < B) { st.done[r] = 0; st.hyp_len[r] = 0; st.hyp_score[r] = 0.f; }
+}
+
 // ---- argmax: one block per row; lowest index wins ties (torch.argmax on CPU) -------------------
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int ld, int V,
                                                      int64_t* __restrict__ out, int ld_out,
@@ -425,6 +513,27 @@ hipError_t launch_beam_topk(const float* logits, int ld, const float* beam_score
     if (B <= 0 || beams <= 0 || beams > 16 || K <= 0 || K > 16 || K > beams * V) return hipErrorInvalidValue;
     if (K <= 8) hipLaunchKernelGGL(beam_topk_kernel<8>, dim3(B), dim3(256), 0, s, logits, ld, beam_scores, beams, V, K, out_scores, out_idx);
     else hipLaunchKernelGGL(beam_topk_kernel<16>, dim3(B), dim3(256), 0, s, logits, ld, beam_scores, beams, V, K, out_scores, out_idx);
+    return hipGetLastError();
+}
+
+hipError_t launch_beam_init(const BeamBuffers& bb, int B, int beams, int max_len, int cls, hipStream_t s) {
+    BeamState st{{bb.ids0, bb.ids1}, bb.beam_scores, bb.words, bb.src_rows, bb.done, bb.hyp_len, bb.hyp_score, bb.hyp_ids};
+    hipLaunchKernelGGL(beam_init_kernel, dim3((B * beams + 63) / 64), dim3(64), 0, s, st, B, beams, max_len, cls);
+    return hipGetLastError();
+}
+
+hipError_t launch_beam_step(const BeamBuffers& bb, const float* cand_scores, const int* cand_idx, int B, int beams, int K,
+                            int V, int cur_len, int max_len, int eos, float length_penalty, int cur, hipStream_t s) {
+    if (beams > 16 || K > 16) return hipErrorInvalidValue;
+    BeamState st{{bb.ids0, bb.ids1}, bb.beam_scores, bb.words, bb.src_rows, bb.done, bb.hyp_len, bb.hyp_score, bb.hyp_ids};
+    hipLaunchKernelGGL(beam_step_kernel, dim3(B), dim3(64), 0, s, st, cand_scores, cand_idx, beams, K, V, cur_len, max_len, eos,
+                       length_penalty, cur);
+    return hipGetLastError();
+}
+
+hipError_t launch_beam_finish(const BeamBuffers& bb, int B, int max_len, int eos, int64_t* decoded, float* logprobs, hipStream_t s) {
+    BeamState st{{bb.ids0, bb.ids1}, bb.beam_scores, bb.words, bb.src_rows, bb.done, bb.hyp_len, bb.hyp_score, bb.hyp_ids};
+    hipLaunchKernelGGL(beam_finish_kernel, dim3(B), dim3(64), 0, s, st, max_len, eos, decoded, logprobs);
     return hipGetLastError();
 }
 

@@ -28,6 +28,7 @@ SYMBOLS = {
     "gitcap_greedy_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "gitcap_preprocess": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gitcap_beam_topk": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gitcap_beam_search": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "gitcap_reorder_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gitcap_profile_enable": (c_int, [c_void_p, c_int]),
     "gitcap_profile_read": (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int64),

@@ -371,19 +371,38 @@ class GitCaptioner(nn.Module):
 
     @torch.no_grad()
     def infer(self, src: torch.Tensor, beam_size: int = 4, max_steps: int = 15, length_penalty: float = 0.6,
-              per_node_beam_size: int = 2, num_keep_best: int = 1, save_logits: bool = False) -> dict:
+              per_node_beam_size: int = 2, num_keep_best: int = 1, save_logits: bool = False,
+              on_device: Optional[bool] = None) -> dict:
         """GIT inference with beam search = ``GenerativeImageTextModel.infer`` (model.py:426-462) driven by
         ``GeneratorWithBeamSearchV2.search`` (model.py:479-678; defaults of :702-708).  Returns the
         reference's output dict: predictions [B, max_steps] (CLS-prefixed, EOS padded), logprobs [B,1],
-        logits_dict (per-step [B*beams, V] host arrays when save_logits, cf. :521) and visual_features."""
+        logits_dict (per-step [B*beams, V] host arrays when save_logits, cf. :521) and visual_features.
+        Default: the device-resident search (no host sync per step); on_device=False runs the host-side
+        operator of gitcap/search.py (needed for num_keep_best > 1 or save_logits)."""
         from .search import GeneratorWithBeamSearch
         if beam_size > self.max_beams:
             raise ValueError(f"beam_size {beam_size} > max_beams={self.max_beams} the handle was created for")
         if max_steps > self.max_text_len:
             raise ValueError(f"max_steps {max_steps} > max_text_len={self.max_text_len}")
         fr = self._frames(src)
+        B, F = fr.shape[:2]
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} > max_batch={self.max_batch}")
+        if on_device is None:
+            on_device = num_keep_best == 1 and not save_logits and beam_size * per_node_beam_size <= 16
+        if on_device:
+            # the whole search on the GPU, no per-step host sync (gitcap_beam_search)
+            if num_keep_best != 1 or save_logits:
+                raise ValueError("the device-resident search keeps one hypothesis and does not export per-step logits")
+            decoded = torch.empty((B, max_steps), dtype=torch.int64, device=self._dev)
+            logprobs = torch.empty((B,), dtype=torch.float32, device=self._dev)
+            with torch.cuda.device(self._dev):
+                self._call("gitcap_beam_search", ctypes.c_void_p(fr.data_ptr()), B, F, beam_size, max_steps,
+                           ctypes.c_float(length_penalty), per_node_beam_size, ctypes.c_void_p(decoded.data_ptr()),
+                           ctypes.c_void_p(logprobs.data_ptr()), self._stream())
+            self._last_memory = None
+            return {"predictions": decoded, "logprobs": logprobs[:, None], "logits_dict": [], "visual_features": None}
         _, vis = self.forward_image_enc(fr)
-        B = fr.shape[0]
         searcher = GeneratorWithBeamSearch(self.sep_token_id, max_steps, beam_size, per_node_beam_size, length_penalty)
         start = torch.full((B, 1), self.cls_token_id, dtype=torch.long, device=self._dev)      # model.py:429-431
 

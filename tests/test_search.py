@@ -113,7 +113,14 @@ def test_device_beam_search_vs_oracle_tiny_model():
     w = synthetic_weights(cfg, 0)
     fr = make_frames(2, 2, cfg.image_size, 21)
     m = GitCaptioner(cfg, w, max_batch=2, max_text_len=10, max_beams=4)
-    out = m.infer(fr, beam_size=4, max_steps=8, length_penalty=0.6)
+    out = m.infer(fr, beam_size=4, max_steps=8, length_penalty=0.6, on_device=False)
+    # device-resident search (gitcap_beam_search): same kernels produce the logits, so it must reproduce the
+    # host-side operator exactly, for several shapes of the search
+    for beams, steps, lp in [(4, 8, 0.6), (2, 6, 1.0), (1, 5, 0.6), (3, 10, 0.0)]:
+        host = m.infer(fr, beam_size=beams, max_steps=steps, length_penalty=lp, on_device=False)
+        dev = m.infer(fr, beam_size=beams, max_steps=steps, length_penalty=lp, on_device=True)
+        assert torch.equal(dev["predictions"], host["predictions"]), (beams, steps, lp)
+        assert torch.allclose(dev["logprobs"].cpu(), host["logprobs"].cpu(), atol=1e-5)
     orc = GitOracle(cfg, w, emulate_bf16=True)
     _, mem = orc.forward_image_enc(fr)
 
