@@ -163,9 +163,9 @@ int gitcap_reorder_rows(gitcap_t* h, const int32_t* src_rows, int rows, int t_le
 enum {
     GITCAP_PROF_GEMM = 0,       /* bf16 MFMA GEMM (patch-embed, qkv, proj, fc1, fc2, vproj) */
     GITCAP_PROF_ATTN_FULL = 1,  /* flash attention over frames / image prefix */
-    GITCAP_PROF_SKINNY = 2,     /* text-row weight-streaming GEMMs (incl. vocabulary head) */
+    GITCAP_PROF_SKINNY = 2,     /* text-row weight-streaming GEMMs (incl. vocabulary head) and their reduce+LayerNorm */
     GITCAP_PROF_ATTN_TEXT = 3,  /* text-row attention over the KV cache */
-    GITCAP_PROF_ROWOPS = 4,     /* LayerNorm */
+    GITCAP_PROF_ROWOPS = 4,     /* LayerNorm over the image rows */
     GITCAP_PROF_CLASSES = 5
 };
 int gitcap_profile_enable(gitcap_t* h, int enable);

@@ -254,7 +254,7 @@ int skinny_splitk(gitcap* h, hipStream_t s, const bf16_t* X, int ldx, const bf16
 
 int ln_reduce(gitcap* h, hipStream_t s, const float* slabs, int nslab, const float* bias, const float* resid,
               const float* g, const float* b, float eps, int M, int D, float* xf, bf16_t* xb) {
-    ProfScope ps(h, GITCAP_PROF_ROWOPS, s, 0.0, (double)M * D * (4.0 * nslab + 4.0 + 6.0));
+    ProfScope ps(h, GITCAP_PROF_SKINNY, s, 0.0, (double)M * D * (4.0 * nslab + 4.0 + 6.0));   // text-path class
     HIP_OK(h, launch_ln_reduce(slabs, nslab, bias, resid, g, b, eps, M, D, xf, xb, s));
     return 0;
 }
