@@ -82,10 +82,11 @@ struct gitcap {
     int cur_B = 0, cur_S = 0;
     bool have_image = false;
 
-    // Four slots (image-prefix K/V, text-row workspace, stop counters, decode stream): while batch
-    // i+2's image pass (MFMA bound) runs on `s_enc`, the token loops of batches i and i+1 (chains of
-    // tiny latency-bound kernels) of the batches before it interleave on their own streams (gitcap_greedy_submit / _wait).
-    // The synchronous entry points always use slot 0 on the caller's stream.
+    // Four slots (image-prefix K/V, text-row workspace, stop counters, decode stream).  While one
+    // batch's image pass (MFMA bound) runs on `s_enc`, the token loops of the batches submitted before
+    // it (chains of tiny latency-bound kernels) interleave on their slots' own streams
+    // (gitcap_greedy_submit / _wait).  The synchronous entry points always use slot 0 on the caller's
+    // stream; do not mix them with submissions that are still in flight.
     struct Slot {
         bf16_t* kv_img = nullptr; int32_t* sep_cnt = nullptr;
         // text-row workspace of the slot (each slot's token loop runs on its own stream)
