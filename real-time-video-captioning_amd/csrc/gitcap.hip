@@ -57,7 +57,7 @@ struct gitcap {
     std::vector<void*> allocs;
 
     // workspace (image rows)
-    float *x = nullptr, *tmp = nullptr, *visual = nullptr;
+    float *x = nullptr, *tmp = nullptr;
     bf16_t *hb = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr, *patches = nullptr, *kv_img = nullptr;
     // workspace (text rows)
     float *xs = nullptr, *slabs = nullptr, *amax_val = nullptr;
@@ -405,7 +405,6 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     const size_t Mi = h->Mi, Mt = h->Mt;
     rc = rc ? rc : ws_alloc(h, &h->x, Mi * Dm);
     rc = rc ? rc : ws_alloc(h, &h->tmp, Mi * h->D);
-    rc = rc ? rc : ws_alloc(h, &h->visual, Mi * h->Dv);
     rc = rc ? rc : ws_alloc(h, &h->hb, Mi * Dm);
     rc = rc ? rc : ws_alloc(h, &h->qkv, Mi * 3 * h->Dv);
     rc = rc ? rc : ws_alloc(h, &h->ctx, Mi * Dm);
@@ -600,9 +599,9 @@ static int encode_impl(gitcap* h, const float* frames, int B, int F, float* visu
     // ln_post (+ per-frame temporal embedding, model.py:380); frames of a clip are already
     // adjacent rows, so the concat along tokens (model.py:382) is the identity on this layout
     const float* addv = c.num_frames > 0 ? h->temporal : nullptr;
-    if ((rc = ln(h, s, h->x, Dv, h->ln_post_w, h->ln_post_b, c.enc_ln_eps, rows, Dv, h->visual, Dv, h->hb, Dv, addv, N, F))) return rc;
-    if (visual_out)
-        HIP_OK(h, hipMemcpyAsync(visual_out, h->visual, (size_t)rows * Dv * 4, hipMemcpyDeviceToDevice, s));
+    // the fp32 visual features (58 MB at B=16, F=6) are written straight into the caller's buffer and only
+    // when asked for; the decoder consumes the bf16 copy
+    if ((rc = ln(h, s, h->x, Dv, h->ln_post_w, h->ln_post_b, c.enc_ln_eps, rows, Dv, visual_out, Dv, h->hb, Dv, addv, N, F))) return rc;
     return image_prefix(h, B, F * N, s);
 }
 
