@@ -12,21 +12,22 @@
 //
 // Schedule ("ping-pong"): waves 0-3 (group 0) and waves 4-7 (group 1) share the SIMDs pairwise
 // and run the SAME program one barrier apart, so while one wave of a SIMD is in a LOAD phase
-// (ds_read_b128 fragment reads + LDS-DMA issue for the next K-tile) its partner is in a COMPUTE
-// phase (16 MFMAs = one 64x32 quadrant over K=64):
+// (LDS-DMA issue for the next K-tiles, lgkmcnt drain) its partner is in a COMPUTE phase
+// (16 MFMAs = one 64x32 quadrant over K=64, with the ds_read_b128 fragment reads of the NEXT
+// quadrant interleaved between the MFMAs by sched_group_barrier):
 //
 //     slot      8t+0   8t+1   8t+2   8t+3   8t+4   8t+5   8t+6   8t+7
 //     group 0   L0(t)  C0(t)  L1(t)  C1(t)  L2(t)  C2(t)  L3(t)  C3(t)
 //     group 1   C3(t-1) L0(t) C0(t)  L1(t)  C1(t)  L2(t)  C2(t)  L3(t)
 //
-//   L0: read W frags of rows N0 (8) + act frags M0 (4)
-//   L1: read act frags M1 (4);        LDS-DMA W-hi(t+1)
-//   L2: read W frags of rows N1 (8);  LDS-DMA A-lo(t+2)
-//   L3:                               LDS-DMA A-hi(t+2), W-lo(t+2); s_waitcnt vmcnt(6)
+//   L0: read act frags M0 (4)                     C0 (N0,M0): + read act frags M1 (4)
+//   L1: LDS-DMA W-hi(t+1)                         C1 (N0,M1): + read W frags N1 (8) -> second register set
+//   L2: LDS-DMA A-lo(t+2)                         C2 (N1,M1)
+//   L3: LDS-DMA A-hi(t+2), W-lo(t+2); vmcnt(6)    C3 (N1,M0): + read W frags N0 of tile t+1 (8)
 //   quadrant order (N0,M0) (N0,M1) (N1,M1) (N1,M0): M0/M1 fragments stay in registers.
 // Every slot ends with one s_barrier executed by all 8 waves.  The LDS-DMA prefetch runs ~1.5
 // K-tiles ahead through only two stages: a half-tile of tile t is overwritten by tile t+2 as soon
-// as both groups are past its last read (A halves: L1(t); W halves: L2(t)).  RAW: the counted
+// as both groups are past its last read (A halves: C0(t); W halves: C1(t)).  RAW: the counted
 // vmcnt(6) in L3(t) retires every DMA of tile t+1 (the six youngest belong to tile t+2) and tile
 // t+1 is first read one barrier later; every LOAD phase drains lgkmcnt before its barrier (WAR).
 //
@@ -101,10 +102,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     // Prefetch runs ~1.5 K-tiles ahead with the 8 DMA instructions of a tile spread over four LOAD
     // phases (2 each), each issued as soon as BOTH groups have finished reading the half-tile it
     // overwrites:   L2(t): A-lo(t+2)   L3(t): A-hi(t+2), W-lo(t+2)   L1(t+1): W-hi(t+2)
-    // (A halves are last read in L1(t), W halves in L2(t); group 1 trails group 0 by one slot.)
+    // (A halves are last read in C0(t), W halves in C1(t); group 1 trails group 0 by one slot.)
     // The only wait is a COUNTED one in L3(t): vmcnt(6) leaves the six youngest DMAs (all of them
     // for tile t+2) in flight and retires everything of tile t+1, which is first read one barrier
-    // later, in L0(t+1).
+    // later, in C3(t) (W-lo rows of tile t+1) and L0(t+1).
     const int nt = a.K >> 6;
 #pragma unroll
     for (int w = 0; w < 4; ++w) dma_half(smem, w, 0);
@@ -119,7 +120,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     BARRIER();
     if (grp == 1) BARRIER();                       // group 1 runs one slot behind group 0
 
-    bf16x8 wf[4][2], af[2][2][2];
+    // Fragment reads are issued one COMPUTE phase ahead of their use (LDS reads between MFMAs are nearly
+    // free), so the LOAD phases only issue LDS-DMA and drain lgkmcnt:
+    //   C0 (N0,M0): + read M1        C1 (N0,M1): + read N1 -> wf2      C2 (N1,M1)
+    //   C3 (N1,M0): + read N0 of tile t+1 -> wf (valid: C3 follows the vmcnt wait + barrier of L3)
+    //   L0: read M0 of this tile (its registers are still in use during the previous C3)
+    bf16x8 wf[4][2], wf2[4][2], af[2][2][2];
+    {
+        const char* sb0 = smem;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wf[i][0] = *(const bf16x8*)(sb0 + offW + i * 2048 + c0);
+            wf[i][1] = *(const bf16x8*)(sb0 + offW + i * 2048 + c1);
+        }
+    }
     for (int t = 0; t < nt; ++t) {
         const char* sb = smem + (t & 1) * STAGE;
         char* cb = smem + (t & 1) * STAGE;          // stage of tile t == stage of tile t+2
@@ -127,12 +141,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
         const bool has1 = (t + 1) < nt, has2 = (t + 2) < nt;
         const int k1 = (t + 1) << 6, k2 = (t + 2) << 6;
 
-        // ---------------- L0: W rows N0, act rows M0 ---------------------------------------------
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            wf[i][0] = *(const bf16x8*)(sb + offW + i * 2048 + c0);
-            wf[i][1] = *(const bf16x8*)(sb + offW + i * 2048 + c1);
-        }
+        // ---------------- L0: act rows M0 ----------------------------------------------------------
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             af[0][j][0] = *(const bf16x8*)(sb + offA + j * 2048 + c0);
@@ -141,8 +150,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
         WAIT_LGKM0();
         SCHED_FENCE();
         BARRIER();
-        // ---------------- C0: (N0, M0) -----------------------------------------------------------
+        // ---------------- C0: (N0, M0); prefetch M1 ------------------------------------------------
         __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            af[1][j][0] = *(const bf16x8*)(sb + offA + 32 * 128 + j * 2048 + c0);
+            af[1][j][1] = *(const bf16x8*)(sb + offA + 32 * 128 + j * 2048 + c1);
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -150,21 +164,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[0][i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], af[0][j][ks], acc[0][i][0][j], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        }
         __builtin_amdgcn_s_setprio(0);
         SCHED_FENCE();
         BARRIER();
-        // ---------------- L1: act rows M1; DMA W-hi of tile t+1 ------------------------------------
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            af[1][j][0] = *(const bf16x8*)(sb + offA + 32 * 128 + j * 2048 + c0);
-            af[1][j][1] = *(const bf16x8*)(sb + offA + 32 * 128 + j * 2048 + c1);
-        }
+        // ---------------- L1: DMA W-hi of tile t+1 --------------------------------------------------
         if (has1) dma_half(nb, 1, k1);
         WAIT_LGKM0();
         SCHED_FENCE();
         BARRIER();
-        // ---------------- C1: (N0, M1) -----------------------------------------------------------
+        // ---------------- C1: (N0, M1); prefetch N1 -------------------------------------------------
         __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wf2[i][0] = *(const bf16x8*)(sb + offW + 64 * 128 + i * 2048 + c0);
+            wf2[i][1] = *(const bf16x8*)(sb + offW + 64 * 128 + i * 2048 + c1);
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -172,20 +191,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[0][i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], af[1][j][ks], acc[0][i][1][j], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        }
         __builtin_amdgcn_s_setprio(0);
         SCHED_FENCE();
         BARRIER();
-        // ---------------- L2: W rows N1; DMA A-lo of tile t+2 --------------------------------------
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            wf[i][0] = *(const bf16x8*)(sb + offW + 64 * 128 + i * 2048 + c0);
-            wf[i][1] = *(const bf16x8*)(sb + offW + 64 * 128 + i * 2048 + c1);
-        }
+        // ---------------- L2: DMA A-lo of tile t+2 ---------------------------------------------------
         if (has2) dma_half(cb, 2, k2);
         WAIT_LGKM0();
         SCHED_FENCE();
         BARRIER();
-        // ---------------- C2: (N1, M1) -----------------------------------------------------------
+        // ---------------- C2: (N1, M1) ---------------------------------------------------------------
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -193,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[1][i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], af[1][j][ks], acc[1][i][1][j], 0, 0, 0);
+                    acc[1][i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[i][ks], af[1][j][ks], acc[1][i][1][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         SCHED_FENCE();
         BARRIER();
@@ -207,15 +226,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
         }
         SCHED_FENCE();
         BARRIER();
-        // ---------------- C3: (N1, M0) -----------------------------------------------------------
+        // ---------------- C3: (N1, M0); prefetch N0 of tile t+1 --------------------------------------
         __builtin_amdgcn_s_setprio(1);
+        // (on the last tile this reads the other stage's stale image: in bounds, never used)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wf[i][0] = *(const bf16x8*)(nb + offW + i * 2048 + c0);
+            wf[i][1] = *(const bf16x8*)(nb + offW + i * 2048 + c1);
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[1][i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], af[0][j][ks], acc[1][i][0][j], 0, 0, 0);
+                    acc[1][i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[i][ks], af[0][j][ks], acc[1][i][0][j], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        }
         __builtin_amdgcn_s_setprio(0);
         SCHED_FENCE();
         BARRIER();
