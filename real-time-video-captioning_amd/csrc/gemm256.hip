@@ -34,12 +34,11 @@
 // LDS image per stage (64 KiB): [W-lo | W-hi | A-lo | A-hi], each 128 rows x 128 B, 16-B chunks
 // XOR-swizzled by (row>>1)&7 on the DMA SOURCE address and again on the read (conflict-free
 // ds_read_b128 for the 16x16x32 operand map, see common.h).
-#include "kernels.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
 constexpr int STAGE = 65536, HALF = 16384;
-constexpr int EPI_REGION = 64 * (64 * 4 + 16);   // per-wave epilogue staging (fp32 worst case): 17408 B
 constexpr int LDS_TOTAL = 8 * EPI_REGION;        // 139264 B >= 2 * STAGE
 
 #define BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
@@ -252,80 +251,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     }
     if (grp == 0) BARRIER();                       // matches group 1's extra leading barrier
 
-    // ---- epilogue through LDS ----------------------------------------------------------------------
-    // The accumulator layout (lane = one m, 4 consecutive n) would scatter 32-byte pieces over 16
-    // rows per store instruction.  Instead every wave transposes its 64(m) x 64(n) half-blocks through
-    // a private LDS region (the operand stages are dead after the last barrier) and writes/reads
-    // global memory as full row segments: 16 B per lane, 128 B (bf16) or 256 B (fp32) per row.
-    constexpr bool OUT_BF16 = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16);
-    constexpr int ESZ = OUT_BF16 ? 2 : 4;
-    constexpr int RS = 64 * ESZ + 16;                      // padded row stride (bytes)
-    constexpr int LPR = 64 * ESZ / 16;                     // lanes per row on the row-wise side (8 or 16)
-    constexpr int RPI = 64 / LPR;                          // rows per wave-instruction (8 or 4)
-    char* ep = smem + wid * EPI_REGION;
-    const int rr = lane / LPR, rc = lane % LPR;            // row-wise role of this lane
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-        const int nb = n0 + wn * 128 + x * 64;             // first n of this half-block
-        // 1) accumulator layout -> LDS [m_local][n_local]
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int nl = i * 16 + fq * 4;
-            f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (EPI != EPI_PATCH_F32 && a.bias) bias4 = *(const f32x4*)(a.bias + nb + nl);
-#pragma unroll
-            for (int y = 0; y < 2; ++y)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int ml = y * 32 + j * 16 + frow;
-                    f32x4 v = acc[x][i][y][j] + bias4;
-                    if (EPI == EPI_BIAS_QGELU_BF16) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
-                    } else if (EPI == EPI_BIAS_GELU_BF16) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = erf_gelu(v[r]);
-                    }
-                    if (OUT_BF16) {
-                        uint2 o;
-                        o.x = pack_bf2(v[0], v[1]);
-                        o.y = pack_bf2(v[2], v[3]);
-                        *(uint2*)(ep + ml * RS + nl * 2) = o;
-                    } else {
-                        *(f32x4*)(ep + ml * RS + nl * 4) = v;
-                    }
-                }
-        }
-        WAIT_LGKM0();
-        // 2) LDS rows -> global, 16 B per lane along n
-#pragma unroll
-        for (int it = 0; it < 64 / RPI; ++it) {
-            const int ml = it * RPI + rr;
-            const int m = m0 + wm * 64 + ml;
-            const int n = nb + rc * (16 / ESZ);
-            const uint4 raw = *(const uint4*)(ep + ml * RS + rc * 16);
-            if (OUT_BF16) {
-                *(uint4*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = raw;
-            } else {
-                f32x4 v = __builtin_bit_cast(f32x4, raw);
-                if (EPI == EPI_BIAS_RESID_F32) {
-                    v += *(const f32x4*)(a.resid + (size_t)m * a.ldr + n);
-                    *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;
-                } else if (EPI == EPI_BIAS_F32) {
-                    *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;
-                } else {  // EPI_PATCH_F32: m = frame*P + patch -> row frame*N + 1 + patch, + pos[1+patch]
-                    if (m < a.valid_rows) {
-                        const int frame = m / a.patches_per_frame;
-                        const int patch = m - frame * a.patches_per_frame;
-                        v += *(const f32x4*)(a.pos + (size_t)(1 + patch) * a.N + n);
-                        const size_t orow = (size_t)frame * a.tokens_per_frame + 1 + patch;
-                        *(f32x4*)((float*)a.out + orow * a.ldo + n) = v;
-                    }
-                }
-            }
-        }
-        WAIT_LGKM0();                                      // reads done before the next half-block overwrites
-    }
+    // ---- epilogue through LDS (gemm_epilogue.h; the operand stages are dead after the last barrier) ----
+    gemm_epilogue_wave<EPI>(a, acc, smem + wid * EPI_REGION, m0 + wm * 64, n0 + wn * 128, lane);
 }
 
 template <int EPI>

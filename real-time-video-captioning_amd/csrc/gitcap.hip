@@ -790,7 +790,8 @@ int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float
     a.A = (const bf16_t*)A; a.lda = K; a.W = (const bf16_t*)W; a.bias = bias; a.M = M; a.N = N; a.K = K;
     a.out = out; a.ldo = N; a.resid = resid; a.ldr = N;
     if (epi < 0 || epi > EPI_BIAS_F32) return GITCAP_ERR_ARG;
-    hipError_t e = (tile == 257) ? launch_gemm256p(a, epi, (hipStream_t)stream)
+    hipError_t e = (tile == 258) ? launch_gemm2b(a, epi, (hipStream_t)stream)
+                 : (tile == 257) ? launch_gemm256p(a, epi, (hipStream_t)stream)
                  : (tile == 256) ? launch_gemm256(a, epi, (hipStream_t)stream) : launch_gemm(a, epi, (hipStream_t)stream);
     return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
 }

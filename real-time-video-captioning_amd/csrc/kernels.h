@@ -25,6 +25,8 @@ hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);      // 128x1
 bool gemm256_ok(const GemmArgs& a);
 hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);   // 256x256 tile, 8-wave ping-pong
 hipError_t launch_gemm256p(const GemmArgs& a, int epi, hipStream_t s);  // same, persistent over tiles
+bool gemm2b_ok(const GemmArgs& a);
+hipError_t launch_gemm2b(const GemmArgs& a, int epi, hipStream_t s);    // 256(n)x128(m) tile, 4 waves, two workgroups per CU
 
 // ---- skinny GEMMs (text rows; M = a few 16-row tiles): weight streaming, one wave per tile ----
 enum SkinnyEpi { SK_BIAS_BF16 = 0, SK_BIAS_GELU_BF16 = 1, SK_BIAS_F32 = 3 };
