@@ -175,7 +175,8 @@ int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launche
 /* Kernel-level test hooks (tests/test_kernels_gpu.py, tools/gemm_bench.py): run ONE kernel on
  * caller-owned device buffers.  gemm: out[m][n] = sum_k A[m][k]*W[n][k] (+epilogue `epi` of
  * csrc/kernels.h: 0 bias->bf16, 1 bias+QuickGELU->bf16, 2 bias+GELU->bf16, 3 bias+resid->f32,
- * 4 bias->f32); A [M][K] bf16, W [N][K] bf16, M % 128 == 0; tile = 128 or 256. */
+ * 4 bias->f32); A [M][K] bf16, W [N][K] bf16, M % 128 == 0; tile = 128, 256 (the product kernel),
+ * 257 (persistent variant) or 258 (two-workgroups-per-CU variant; both measured experiments). */
 int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float* resid, void* out,
                     int M, int N, int K, int epi, int tile, void* stream);
 /* attn_full: qkv [G*S][3*H*64] bf16 -> ctx [G*S][H*64] bf16 */
@@ -187,6 +188,47 @@ int gitcap_dbg_layernorm(const float* x, const float* gamma, const float* beta, 
 /* Introspection used by tests and bench.py */
 int gitcap_workspace_bytes(const gitcap_t* h, int64_t* bytes);
 int gitcap_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Student decoder (SURVEY.md par. 8 row f.2): StudentCandidateV1, src/models/model.py:50-187 --
+ * torch.nn.TransformerDecoder (post-LN, ReLU; model.py:82-85) over the caption so far (causal mask,
+ * PAD tokens masked as keys; model.py:134-136, src/utils/masking.py) with cross-attention over
+ * `memory` = one token per frame (model.py:124), embedding + positional table / sqrt(d_model)
+ * (model.py:140-144, :320-340) and a Linear vocabulary head (model.py:152).  The TinyViT image encoder
+ * (timm, model.py:38) is NOT behind this ABI: the caller supplies memory [B][mem_tokens][d_model].
+ * Tensor names are the reference's state_dict keys (embed.weight, pos_enc.pe,
+ * decoder.layers.{i}.self_attn.in_proj_weight, ..., linear.weight, linear.bias); same ownership, error
+ * and threading rules as the gitcap_* entry points above.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct gitcap_student gitcap_student_t;
+struct gitcap_student_config {
+    int32_t d_model, n_head, d_ffn, num_layers;      /* config.py:79-83: 576, 8, 1024, 2 */
+    int32_t vocab_size, cls_token_id, sep_token_id;  /* 30522, 101, 102 */
+    int32_t pad_token_id;                            /* 0: create_padding_mask default, masking.py:4 */
+    int32_t mem_tokens;                              /* frames per clip (6) */
+    int32_t max_pos;                                 /* rows of the positional table (500, model.py:324) */
+    int32_t max_rows;                                /* largest batch the workspace is sized for */
+    int32_t max_text_len;                            /* largest max_len of greedy / T-1 of forward_decoder (<= 63) */
+    float ln_eps;                                    /* 1e-5 */
+};
+/* StudentCandidateV1.__init__ (model.py:55-106) for the decoder part */
+int gitcap_student_create(const struct gitcap_student_config* cfg, int device, gitcap_student_t** out);
+void gitcap_student_destroy(gitcap_student_t* h);
+const char* gitcap_student_last_error(const gitcap_student_t* h);
+/* load_state_dict (src/inference.py:38): host fp32 data, logical shape; GEMM weights are stored as bf16 */
+int gitcap_student_load_tensor(gitcap_student_t* h, const char* name, const float* data, const int64_t* shape, int rank);
+int gitcap_student_finalize(gitcap_student_t* h);
+/* memory: device fp32 [B][mem_tokens][d_model] (model.py:124) -> bf16 + the cross-attention K/V of every layer */
+int gitcap_student_set_memory(gitcap_student_t* h, const float* memory, int B, void* stream);
+/* forward_decoder (model.py:128-154): ids device int64 [B][ld_ids] (T valid columns) -> logits device fp32
+ * [B][T][vocab].  Needs a preceding set_memory with the same B.  A row whose first token is PAD yields NaN
+ * for that position, as torch does (every key masked). */
+int gitcap_student_forward_decoder(gitcap_student_t* h, const int64_t* ids, int ld_ids, int B, int T, float* logits, void* stream);
+/* greedy_decode (model.py:156-187) from memory: ids_out device int64 [B][max_len+1], CLS-prefixed; the
+ * token loop runs on the device with an exact KV cache; steps_out (device int32[1], nullable) = number of
+ * generated tokens under the stop rule (enum gitcap_stop; GITCAP_STOP_ALL_SEP = model.py:184). */
+int gitcap_student_greedy(gitcap_student_t* h, const float* memory, int B, int max_len, int stop,
+                          int64_t* ids_out, int32_t* steps_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,7 @@
 // Declarations and the reference call each entry point replaces: include/gitcap.h.
 #include "../../include/gitcap.h"
 #include "kernels.h"
+#include "host_util.h"
 
 #include <cmath>
 #include <cstdio>
@@ -14,23 +15,6 @@
 #define GITCAP_ABI_VERSION 1
 
 namespace {
-
-struct DevTensor {
-    void* p = nullptr;
-    std::vector<int64_t> shape;   // logical (unpadded) shape
-    bool bf16 = false;
-    bool loaded = false;
-};
-
-inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
-
-uint16_t host_f2bf(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
 
 struct EncLayer {
     const float *ln1w, *ln1b, *ln2w, *ln2b, *qkvb, *projb, *fc1b, *fc2b;
@@ -139,16 +123,6 @@ void select_slot(gitcap* h, int i) {
             return fail(h, GITCAP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));        \
     } while (0)
 
-// Makes the handle's device current for the duration of an entry point and restores the caller's.
-struct DeviceGuard {
-    int prev = -1; bool ok = true;
-    explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
-        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
-        if (prev == dev) prev = -1;
-    }
-    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
 #define GUARD(h) DeviceGuard guard_((h)->device); if (!guard_.ok) return fail(h, GITCAP_ERR_HIP, "cannot select the handle's device")
 
 struct ProfScope {

@@ -29,7 +29,7 @@ bool gemm2b_ok(const GemmArgs& a);
 hipError_t launch_gemm2b(const GemmArgs& a, int epi, hipStream_t s);    // 256(n)x128(m) tile, 4 waves, two workgroups per CU
 
 // ---- skinny GEMMs (text rows; M = a few 16-row tiles): weight streaming, one wave per tile ----
-enum SkinnyEpi { SK_BIAS_BF16 = 0, SK_BIAS_GELU_BF16 = 1, SK_BIAS_F32 = 3 };
+enum SkinnyEpi { SK_BIAS_BF16 = 0, SK_BIAS_GELU_BF16 = 1, SK_BIAS_RELU_BF16 = 2, SK_BIAS_F32 = 3 };
 struct SkinnyArgs {
     const bf16_t* X; int ldx;     // bf16 activations, row m at X + m*ldx
     const bf16_t* W;              // [Npad16][K]
@@ -64,6 +64,23 @@ struct TextAttnArgs {
     int rows, beams, t0, T, Tmax, S_img, H, D;
 };
 hipError_t launch_attn_text(const TextAttnArgs& a, hipStream_t s);
+
+// Small attention of the student decoder (student.hip): one wave per (query row, head), at most 64 keys,
+// any head_dim that is a multiple of 8 (<= 128).  Query m = (r, j), r = m / T: q at
+// q + (r*q_row_stride + q_row_off + j)*ldq + h*hd; key/value i of row r at k|v + (r*keys_stride + i)*ldkv + h*hd.
+// nkeys > 0: every query sees keys 0..nkeys-1 (cross-attention); nkeys == 0: causal, keys 0..t0+j.
+// ids != nullptr: key i of row r is masked when ids[r*ld_ids + i] == pad_id (all keys masked -> NaN, as torch).
+struct SmallAttnArgs {
+    const bf16_t* q; int ldq, T, q_row_stride, q_row_off;
+    const bf16_t* k; const bf16_t* v; int ldkv, keys_stride, nkeys, t0;
+    const int64_t* ids; int ld_ids, pad_id;
+    bf16_t* ctx; int ldc;
+    int M, H, hd;
+};
+hipError_t launch_attn_small(const SmallAttnArgs& a, hipStream_t s);
+// x[m] = (embed[ids[r*ld_ids + t0 + j]] + pe[t0 + j]) / sqrt(D), m = r*T + j  -> xf (fp32) and xb (bf16)
+hipError_t launch_student_embed(const int64_t* ids, int ld_ids, int rows, int T, int t0, const float* embed,
+                                const float* pe, int D, int vocab, float* xf, bf16_t* xb, hipStream_t s);
 
 // ---- row ops -----------------------------------------------------------------------------
 struct LnArgs {

@@ -54,8 +54,11 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
         if (EPI == SK_BIAS_GELU_BF16) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = erf_gelu(y[r]);
+        } else if (EPI == SK_BIAS_RELU_BF16) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.f);
         }
-        if (EPI == SK_BIAS_BF16 || EPI == SK_BIAS_GELU_BF16) {
+        if (EPI == SK_BIAS_BF16 || EPI == SK_BIAS_GELU_BF16 || EPI == SK_BIAS_RELU_BF16) {
             if (mvalid) {
                 const int orow = (m / a.T) * a.row_stride + a.row_off + (m % a.T);
                 bf16_t* op = (bf16_t*)a.out + (size_t)orow * a.ldo + n;
@@ -133,6 +136,7 @@ hipError_t launch_full(const SkinnyArgs& a, int epi, hipStream_t s) {
     switch (epi) {
         case SK_BIAS_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16>), dim3(grid), dim3(64), 0, s, a); break;
         case SK_BIAS_GELU_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_GELU_BF16>), dim3(grid), dim3(64), 0, s, a); break;
+        case SK_BIAS_RELU_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_RELU_BF16>), dim3(grid), dim3(64), 0, s, a); break;
         case SK_BIAS_F32: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_F32>), dim3(grid), dim3(64), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
@@ -144,17 +148,24 @@ hipError_t launch_full(const SkinnyArgs& a, int epi, hipStream_t s) {
 hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s) {
     if (a.K % 32 || a.M <= 0 || a.T <= 0) return hipErrorInvalidValue;
     switch (a.K / 32) {
+        case 2: return launch_full<2>(a, epi, s);      // K = 64  (tiny student test config)
         case 4: return launch_full<4>(a, epi, s);      // K = 128 (tiny test config)
         case 8: return launch_full<8>(a, epi, s);      // K = 256
+        case 18: return launch_full<18>(a, epi, s);    // K = 576 (student decoder)
         case 24: return launch_full<24>(a, epi, s);    // K = 768
         case 32: return launch_full<32>(a, epi, s);    // K = 1024
     }
     return hipErrorInvalidValue;
 }
 
+// K slabs: 16 for the K >= 2048 matrices, else the largest of 4, 3, 2 that leaves a supported per-slab depth
+// (768 -> 4 x 6, 3072 -> 16 x 6, 1024 -> 4 x 8; student decoder: 576 -> 3 x 6)
 int skinny_ksplit(int K) {
-    const int ks = K >= 2048 ? 16 : 4;
-    return (K % (ks * 32) == 0) ? ks : 0;
+    auto ok = [&](int ks) { const int k32 = K / (ks * 32); return K % (ks * 32) == 0 && (k32 == 1 || k32 == 2 || k32 == 6 || k32 == 8); };
+    if (K >= 2048) return ok(16) ? 16 : 0;
+    for (int ks = 4; ks >= 1; --ks)
+        if (ok(ks)) return ks;
+    return 0;
 }
 
 hipError_t launch_skinny_splitk(const SkinnyArgs& a, hipStream_t s) {

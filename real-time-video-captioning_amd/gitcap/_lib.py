@@ -7,6 +7,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 from .config import CGitCapConfig
+from .student_config import CStudentConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgitcap.so")
@@ -37,6 +38,15 @@ SYMBOLS = {
     "gitcap_dbg_attn_full": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gitcap_dbg_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gitcap_workspace_bytes": (c_int, [c_void_p, POINTER(c_int64)]),
+    # student decoder (gitcap/student.py)
+    "gitcap_student_create": (c_int, [POINTER(CStudentConfig), c_int, POINTER(c_void_p)]),
+    "gitcap_student_destroy": (None, [c_void_p]),
+    "gitcap_student_last_error": (c_char_p, [c_void_p]),
+    "gitcap_student_load_tensor": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
+    "gitcap_student_finalize": (c_int, [c_void_p]),
+    "gitcap_student_set_memory": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "gitcap_student_forward_decoder": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "gitcap_student_greedy": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None
