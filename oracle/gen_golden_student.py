@@ -60,6 +60,35 @@ class TorchStudentDecoder(nn.Module):
         return tgt
 
 
+    def beam_search(self, memory, max_len, k):
+        """Loop-for-loop restatement of model.py:189-318 (all_candidates table, per-(b, idx) copy) -- kept
+        deliberately unlike the oracle's vectorised form so the two check each other."""
+        B = memory.shape[0]
+        tgt = torch.full((B, 1), self.cfg.cls_token_id, dtype=torch.long)
+        sequences = tgt.unsqueeze(1).expand(-1, k, -1)
+        all_candidates = torch.empty(B, k * k, 3)
+        log_probs = torch.log_softmax(self.forward_decoder(tgt, memory)[:, -1, :], dim=-1)
+        scores, top_indices = log_probs.topk(k, dim=-1)
+        sequences = torch.cat([sequences, top_indices.unsqueeze(-1)], dim=-1)
+        for step in range(2, max_len):
+            for i in range(k):
+                log_probs = torch.log_softmax(self.forward_decoder(sequences[:, i], memory)[:, -1, :], dim=-1)
+                top_scores, top_indices = log_probs.topk(k, dim=-1)
+                all_candidates[:, i * k:(i + 1) * k, 0] = scores[:, i].unsqueeze(-1) + top_scores
+                all_candidates[:, i * k:(i + 1) * k, 1] = i
+                all_candidates[:, i * k:(i + 1) * k, 2] = top_indices
+            order = all_candidates[:, :, 0].sort(dim=1, descending=True).indices[:, :k]
+            new_sequences = torch.zeros(B, k, step + 1, dtype=torch.long)
+            for b in range(B):
+                for idx in range(k):
+                    g = order[b, idx]
+                    new_sequences[b, idx, :-1] = sequences[b, all_candidates[b, g, 1].long(), :]
+                    new_sequences[b, idx, -1] = all_candidates[b, g, 2].long()
+                    scores[b, idx] = all_candidates[b, g, 0]
+            sequences = new_sequences
+        return sequences[torch.arange(B), scores.argmax(dim=-1)]
+
+
 @torch.no_grad()
 def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
@@ -71,7 +100,8 @@ def main():
     mem = make_memory(3, cfg.mem_tokens, cfg.d_model, 11)
     y = torch.tensor([[1, 5, 9, 33, 7, 2], [1, 77, 0, 15, 0, 4], [1, 3, 3, 0, 0, 0]])
     np.savez(os.path.join(out_dir, "student_tiny.npz"), mem_seed=11, y=y.numpy(), logits=m.forward_decoder(y, mem).numpy(),
-             greedy_ids=m.greedy(mem, 12, stop_all_sep=False).numpy())
+             greedy_ids=m.greedy(mem, 12, stop_all_sep=False).numpy(), beam_k3=m.beam_search(mem, 9, 3).numpy(),
+             beam_k4=m.beam_search(mem, 6, 4).numpy())
     # a head bias that makes PAD (0) the arg-max at every step: later steps see all earlier keys but CLS masked
     w2 = dict(w); w2["linear.bias"] = w["linear.bias"].copy(); w2["linear.bias"][cfg.pad_token_id] = 50.0
     m.load(w2)

@@ -108,6 +108,31 @@ class StudentOracle:
         return (tgt, torch.stack(steps, 1)) if return_logits else tgt
 
 
+    def beam_search(self, memory: torch.Tensor, max_len: int = 10, k: int = 3) -> torch.Tensor:
+        """model.py:189-318 given ``memory``: k beams, no end-of-sequence handling, every beam proposes its
+        top-k continuations, the k best of the k*k candidates survive; returns the best beam [B, max_len]."""
+        c = self.cfg
+        B = memory.shape[0]
+        tgt = torch.full((B, 1), c.cls_token_id, dtype=torch.long)
+        logp = torch.log_softmax(self.forward_decoder(tgt, memory)[:, -1], dim=-1)        # model.py:221-225
+        scores, top = logp.topk(k, dim=-1)
+        seqs = torch.cat([tgt.unsqueeze(1).expand(-1, k, -1), top.unsqueeze(-1)], dim=-1)  # model.py:227
+        for _ in range(2, max_len):                                                        # model.py:230
+            cand, toks = [], []
+            for i in range(k):                                                             # model.py:232-249
+                lp = torch.log_softmax(self.forward_decoder(seqs[:, i], memory)[:, -1], dim=-1)
+                ts, ti = lp.topk(k, dim=-1)
+                cand.append(scores[:, i:i + 1] + ts)
+                toks.append(ti)
+            cand, toks = torch.cat(cand, dim=1), torch.cat(toks, dim=1)                    # [B, k*k], beam-major
+            sel = cand.sort(dim=1, descending=True).indices[:, :k]                         # model.py:252-256
+            beam = sel // k
+            seqs = torch.cat([seqs.gather(1, beam.unsqueeze(-1).expand(-1, -1, seqs.shape[-1])),
+                              toks.gather(1, sel).unsqueeze(-1)], dim=-1)                  # model.py:259-275
+            scores = cand.gather(1, sel)
+        return seqs[torch.arange(B), scores.argmax(dim=-1)]                                # model.py:317
+
+
 def make_memory(B: int, F: int, D: int, seed: int) -> torch.Tensor:
     """Seeded stand-in for the spatially averaged TinyViT features (model.py:124), O(1) magnitude."""
     g = torch.Generator().manual_seed(seed)

@@ -209,3 +209,33 @@ class StudentCaptioner(nn.Module):
         return ids.to(out_dev) if out_dev != ids.device else ids
 
     generate = greedy_decode
+
+    @torch.no_grad()
+    def beam_search(self, src: torch.Tensor, max_len: int = 10, k: int = 3) -> torch.Tensor:
+        """model.py:189-318: k beams without end-of-sequence handling; returns the best beam [B, max_len].
+        The k beams of a clip are rows of one ``forward_decoder`` call (B*k <= max_batch); like the
+        reference, every step recomputes the whole prefix."""
+        out_dev = src.device
+        memory = self.forward_image_enc(src)[1] if src.dim() == 5 else src
+        mem = self._memory(memory)
+        B = mem.shape[0]
+        if B * k > self.max_batch:
+            raise ValueError(f"B*k={B * k} rows > max_batch={self.max_batch}")
+        if max_len - 1 > self.max_text_len:
+            raise ValueError(f"max_len={max_len} exceeds max_text_len+1={self.max_text_len + 1}")
+        tgt = torch.full((B, 1), self.cls_token_id, dtype=torch.long, device=self._dev)
+        logp = torch.log_softmax(self.forward_decoder(tgt, mem)[:, -1], dim=-1)            # model.py:221-225
+        scores, top = logp.topk(k, dim=-1)
+        seqs = torch.cat([tgt.unsqueeze(1).expand(-1, k, -1), top.unsqueeze(-1)], dim=-1)  # [B, k, 2]
+        mem_rep = mem.repeat_interleave(k, dim=0)                                          # row b*k + i = beam i of clip b
+        for _ in range(2, max_len):                                                        # model.py:230
+            lp = torch.log_softmax(self.forward_decoder(seqs.reshape(B * k, -1), mem_rep)[:, -1], dim=-1)
+            ts, ti = lp.view(B, k, -1).topk(k, dim=-1)                                     # each beam's top-k
+            cand = (scores.unsqueeze(-1) + ts).view(B, k * k)                              # beam-major, as all_candidates
+            sel = cand.sort(dim=1, descending=True).indices[:, :k]                         # model.py:252-256
+            beam = sel // k
+            seqs = torch.cat([seqs.gather(1, beam.unsqueeze(-1).expand(-1, -1, seqs.shape[-1])),
+                              ti.view(B, k * k).gather(1, sel).unsqueeze(-1)], dim=-1)
+            scores = cand.gather(1, sel)
+        best = seqs[torch.arange(B, device=self._dev), scores.argmax(dim=-1)]              # model.py:317
+        return best.to(out_dev) if out_dev != best.device else best

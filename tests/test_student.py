@@ -24,6 +24,19 @@ def test_tiny_oracle_matches_torch_decoder(golden_dir):
     assert np.array_equal(orc.greedy_decode(mem, 12, stop="never").numpy(), g["greedy_ids"])
 
 
+def test_oracle_beam_search_matches_loop_restatement(golden_dir):
+    """model.py:189-318: the oracle's vectorised beam search vs the loop-for-loop restatement over the
+    torch modules (oracle/gen_golden_student.py)."""
+    cfg = student_tiny()
+    g = np.load(os.path.join(golden_dir, "student_tiny.npz"))
+    orc = StudentOracle(cfg, student_synthetic_weights(cfg, 0))
+    mem = make_memory(3, cfg.mem_tokens, cfg.d_model, int(g["mem_seed"]))
+    assert np.array_equal(orc.beam_search(mem, 9, 3).numpy(), g["beam_k3"]) and g["beam_k3"].shape == (3, 9)
+    assert np.array_equal(orc.beam_search(mem, 6, 4).numpy(), g["beam_k4"])
+    # beam 1 degenerates to greedy
+    assert np.array_equal(orc.beam_search(mem, 9, 1).numpy(), orc.greedy_decode(mem, 8, stop="never").numpy())
+
+
 def test_pad_tokens_are_masked_as_keys(golden_dir):
     """model.py:134 + masking.py:14: a generated PAD (id 0) is never attended to afterwards."""
     cfg = student_tiny()
@@ -196,3 +209,28 @@ def test_gpu_stop_rule_pickle_and_errors():
     sd["image_encoder.model.stem.weight"] = torch.zeros(1)          # foreign keys of a reference checkpoint are ignored
     m.load_state_dict(sd)                                           # pos_enc.pe rebuilt from the formula
     assert m.greedy_decode(mem, max_len=8, stop="never").shape == (2, 9)
+
+
+@pytest.mark.gpu
+def test_gpu_beam_search(golden_dir):
+    """k beams as rows of the HIP forward_decoder; compared with the bf16-emulating oracle step by step
+    (teacher-forced on the device's own beams, so a near-tie cannot cascade) and with the goldens."""
+    cfg = student_tiny()
+    w = student_synthetic_weights(cfg, 0)
+    g = np.load(os.path.join(golden_dir, "student_tiny.npz"))
+    m = _student(cfg, w, max_batch=12, max_text_len=12)
+    mem = make_memory(3, cfg.mem_tokens, cfg.d_model, int(g["mem_seed"]))
+    got = m.beam_search(mem, max_len=9, k=3)
+    assert got.shape == (3, 9) and bool((got[:, 0] == cfg.cls_token_id).all())
+    assert torch.equal(m.beam_search(mem, max_len=9, k=1), m.greedy_decode(mem, max_len=8, stop="never"))
+    emu = StudentOracle(cfg, w, emulate_bf16=True)
+    want = emu.beam_search(mem, 9, 3)
+    # sequence log-probability of both winners under the oracle: the device's choice must be as good as the
+    # oracle's up to bf16 noise (identical sequences in the common case)
+    def seq_logp(ids):
+        lp = torch.log_softmax(emu.forward_decoder(ids[:, :-1], mem), dim=-1)
+        return lp.gather(2, ids[:, 1:].unsqueeze(-1)).squeeze(-1).sum(dim=1)
+    assert (seq_logp(got) - seq_logp(want)).abs().max().item() < 0.25
+    assert (got == torch.from_numpy(g["beam_k3"])).float().mean().item() > 0.8
+    with pytest.raises(ValueError):
+        m.beam_search(make_memory(5, cfg.mem_tokens, cfg.d_model, 1), max_len=5, k=3)      # 15 rows > max_batch
