@@ -1,0 +1,38 @@
+# Builds tools/libgitcap_diag.so: a copy of csrc/ with s_memtime / s_memrealtime / HW_ID stamps in gemm256
+# (read by tools/gemm_timeline.py through GEMM_DBG_PTR).  The product library is never instrumented.
+import os, shutil, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tmp = tempfile.mkdtemp(prefix='gitcap_diag_')
+os.makedirs(os.path.join(tmp, 'pkg', 'gitcap')); os.makedirs(os.path.join(tmp, 'include'))
+src = os.path.join(ROOT, 'real-time-video-captioning_amd', 'csrc')
+dst = os.path.join(tmp, 'pkg', 'csrc')
+shutil.copytree(src, dst, ignore=shutil.ignore_patterns('build'))
+shutil.copy(os.path.join(ROOT, 'include', 'gitcap.h'), os.path.join(tmp, 'include'))
+def patch(path, pairs):
+    s = open(path).read()
+    for old, new in pairs:
+        assert s.count(old) == 1, (path, old)
+        s = s.replace(old, new)
+    open(path, 'w').write(s)
+patch(os.path.join(dst, 'gemm256.hip'), [
+    ("    const int nt = a.K >> 6;\n", "    const int nt = a.K >> 6;\n    unsigned long long T0 = __builtin_amdgcn_s_memtime();\n    unsigned long long R0 = __builtin_amdgcn_s_memrealtime();\n"),
+    ("    BARRIER();\n    if (grp == 1) BARRIER();", "    BARRIER();\n    unsigned long long T1 = __builtin_amdgcn_s_memtime();\n    if (grp == 1) BARRIER();"),
+    ("    if (grp == 0) BARRIER();                       // matches group 1's extra leading barrier\n",
+     "    if (grp == 0) BARRIER();                       // matches group 1's extra leading barrier\n    unsigned long long T2 = __builtin_amdgcn_s_memtime();\n"),
+    ("    gemm_epilogue_wave<EPI>(a, acc, smem + wid * EPI_REGION, m0 + wm * 64, n0 + wn * 128, lane);\n",
+     "    gemm_epilogue_wave<EPI>(a, acc, smem + wid * EPI_REGION, m0 + wm * 64, n0 + wn * 128, lane);\n"
+     "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    unsigned long long T3 = __builtin_amdgcn_s_memtime();\n"
+     "    if (EPI != EPI_PATCH_F32 && a.pos && lane == 0) {\n"
+     "        unsigned long long* d = (unsigned long long*)a.pos + ((size_t)blockIdx.x * 8 + wid) * 8;\n"
+     "        d[0] = T0; d[1] = T1; d[2] = T2; d[3] = T3;\n"
+     "        d[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID\n"
+     "        d[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID\n"
+     "        d[6] = R0; d[7] = __builtin_amdgcn_s_memrealtime();\n    }\n"),
+])
+patch(os.path.join(dst, 'gitcap.hip'), [
+    ("    hipError_t e = (tile == 258)", "    if (getenv(\"GEMM_DBG_PTR\")) a.pos = (const float*)strtoull(getenv(\"GEMM_DBG_PTR\"), nullptr, 0);\n    hipError_t e = (tile == 258)"),
+])
+subprocess.check_call(['make', '-C', dst, '-j8'])
+shutil.copy(os.path.join(tmp, 'pkg', 'gitcap', 'libgitcap.so'), os.path.join(ROOT, 'tools', 'libgitcap_diag.so'))
+shutil.rmtree(tmp)
+print('wrote tools/libgitcap_diag.so')
