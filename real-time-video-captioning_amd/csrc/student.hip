@@ -14,6 +14,7 @@
 #include "host_util.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -114,6 +115,13 @@ struct gitcap_student {
     int* amax_idx = nullptr;
     bf16_t *xb = nullptr, *qc = nullptr, *ctx = nullptr, *ffn = nullptr, *kvs = nullptr, *memb = nullptr, *memkv = nullptr;
     int32_t* sep_cnt = nullptr;
+    // greedy loop captured as a hipGraph (one per (B, max_len, stop)); it works on the handle's own
+    // ids / steps buffers, which are copied to the caller's after the replay
+    int64_t* g_ids = nullptr;
+    int32_t* g_steps = nullptr;
+    struct GreedyGraph { int B, max_len, stop; hipGraphExec_t exec; };
+    std::vector<GreedyGraph> graphs;
+    hipStream_t cap_stream = nullptr;   // capture only (the legacy default stream cannot be captured); replays run on the caller's stream
     // resolved weights
     const float *embed = nullptr, *pe = nullptr, *head_b = nullptr;
     const bf16_t* head_w = nullptr;
@@ -308,6 +316,8 @@ void gitcap_student_destroy(gitcap_student_t* h) {
     DeviceGuard g(h->device);
     for (auto& kv : h->w)
         if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     for (void* p : h->allocs) (void)hipFree(p);
     delete h;
 }
@@ -349,6 +359,8 @@ int gitcap_student_finalize(gitcap_student_t* h) {
         if (!kv.second.loaded) return sfail(h, GITCAP_ERR_STATE, "student_finalize: tensor '" + kv.first + "' was never loaded");
     auto Fp = [&](const std::string& n) { return (const float*)h->w[n].p; };
     auto Wt = [&](const std::string& n) { return (const bf16_t*)h->w[n].p; };
+    for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);     // weight pointers are baked into the nodes
+    h->graphs.clear();
     h->embed = Fp("embed.weight"); h->pe = Fp("pos_enc.pe"); h->head_w = Wt("linear.weight"); h->head_b = Fp("linear.bias");
     h->layers.resize(h->L);
     for (int i = 0; i < h->L; ++i) {
@@ -374,7 +386,8 @@ int gitcap_student_finalize(gitcap_student_t* h) {
             (rc = s_alloc(h, &h->slabs, (size_t)ks * Mt * D)) || (rc = s_alloc(h, &h->amax_val, Mt * ntiles)) ||
             (rc = s_alloc(h, &h->amax_idx, Mt * ntiles)) || (rc = s_alloc(h, &h->kvs, (size_t)h->L * Mt * 3 * D)) ||
             (rc = s_alloc(h, &h->memb, (size_t)h->R * h->F * D)) ||
-            (rc = s_alloc(h, &h->memkv, (size_t)h->L * h->R * h->F * 2 * D)) || (rc = s_alloc(h, &h->sep_cnt, (size_t)h->Tmax + 1)))
+            (rc = s_alloc(h, &h->memkv, (size_t)h->L * h->R * h->F * 2 * D)) || (rc = s_alloc(h, &h->sep_cnt, (size_t)h->Tmax + 1)) ||
+            (rc = s_alloc(h, &h->g_ids, (size_t)h->R * h->Tmax)) || (rc = s_alloc(h, &h->g_steps, (size_t)1)))
             return rc;
     }
     h->finalized = true;
@@ -402,14 +415,45 @@ int gitcap_student_greedy(gitcap_student_t* h, const float* memory, int B, int m
     if (stop != GITCAP_STOP_NEVER && stop != GITCAP_STOP_ALL_SEP) return sfail(h, GITCAP_ERR_ARG, "student_greedy: unknown stop rule");
     S_GUARD(h);
     hipStream_t s = (hipStream_t)stream;
-    int rc = set_memory(h, memory, B, s);
+    int rc = set_memory(h, memory, B, s);           // reads the caller's buffer: outside the graph
     if (rc) return rc;
     const int ld = max_len + 1;
-    S_HIP_OK(h, launch_fill_i64(ids_out, ld, B, h->c.cls_token_id, s));                 // model.py:171
-    S_HIP_OK(h, hipMemsetAsync(h->sep_cnt, 0, ((size_t)h->Tmax + 1) * 4, s));
-    for (int t = 0; t < max_len; ++t)                                                    // model.py:173-182
-        if ((rc = text_forward(h, ids_out, ld, B, t, 1, nullptr, ids_out + t + 1, ld, h->sep_cnt, t, s))) return rc;
-    if (steps_out) S_HIP_OK(h, launch_finish_steps(h->sep_cnt, B, max_len, stop, steps_out, s));   // model.py:184
+    // The token loop is launch-latency bound (26 kernels per token): it is captured once per (B, max_len, stop)
+    // and replayed.  GITCAP_STUDENT_GRAPH=0 launches it kernel by kernel (same kernels, same results).
+    static const bool use_graph = !(getenv("GITCAP_STUDENT_GRAPH") && atoi(getenv("GITCAP_STUDENT_GRAPH")) == 0);
+    auto enqueue_loop = [&](hipStream_t q) -> int {
+        S_HIP_OK(h, launch_fill_i64(h->g_ids, ld, B, h->c.cls_token_id, q));                 // model.py:171
+        S_HIP_OK(h, hipMemsetAsync(h->sep_cnt, 0, ((size_t)h->Tmax + 1) * 4, q));
+        for (int t = 0; t < max_len; ++t) {                                                  // model.py:173-182
+            int r = text_forward(h, h->g_ids, ld, B, t, 1, nullptr, h->g_ids + t + 1, ld, h->sep_cnt, t, q);
+            if (r) return r;
+        }
+        S_HIP_OK(h, launch_finish_steps(h->sep_cnt, B, max_len, stop, h->g_steps, q));       // model.py:184
+        return 0;
+    };
+    if (use_graph) {
+        hipGraphExec_t exec = nullptr;
+        for (auto& g : h->graphs)
+            if (g.B == B && g.max_len == max_len && g.stop == stop) exec = g.exec;
+        if (!exec) {
+            hipGraph_t graph = nullptr;
+            if (!h->cap_stream) S_HIP_OK(h, hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+            S_HIP_OK(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_loop(h->cap_stream);
+            hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            S_HIP_OK(h, e);
+            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            S_HIP_OK(h, e);
+            h->graphs.push_back({B, max_len, stop, exec});
+        }
+        S_HIP_OK(h, hipGraphLaunch(exec, s));
+    } else if ((rc = enqueue_loop(s))) {
+        return rc;
+    }
+    S_HIP_OK(h, hipMemcpyAsync(ids_out, h->g_ids, (size_t)B * ld * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    if (steps_out) S_HIP_OK(h, hipMemcpyAsync(steps_out, h->g_steps, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     return 0;
 }
 
