@@ -25,7 +25,7 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-@pytest.mark.parametrize("tile", [128, 256, 257])      # 257 = persistent 256x256 kernel
+@pytest.mark.parametrize("tile", [128, 256, 257, 258])  # 257 = persistent 256x256 kernel, 258 = two workgroups per CU
 @pytest.mark.parametrize("M,N,K,epi", [(512, 768, 768, 0), (256, 256, 64, 4), (768, 2304, 768, 0),
                                        (512, 3072, 768, 1), (512, 3072, 768, 2), (512, 768, 3072, 3),
                                        (256, 1536, 768, 0), (1024, 1024, 1024, 3)])
@@ -57,10 +57,30 @@ def test_gemm_identity_weight_asymmetric_input(lib):
     M = N = K = 256
     A = torch.arange(M * K, device="cuda", dtype=torch.float32).reshape(M, K).remainder(251).bfloat16()
     W = torch.eye(N, K, device="cuda").bfloat16()
-    for tile in (128, 256, 257):
+    for tile in (128, 256, 257, 258):
         out = torch.empty(M, N, device="cuda", dtype=torch.float32)
         assert lib.gitcap_dbg_gemm(_p(A), _p(W), None, None, _p(out), M, N, K, 4, tile, _stream()) == 0
         assert torch.equal(out, A.float())
+
+
+def test_gemm_tile_variants_are_bitwise_equal(lib):
+    """Every tile kernel accumulates each output over ascending k with the same MFMA, so the 128x128
+    fallback, the persistent and the two-workgroup variants must reproduce the product kernel bit for bit
+    (this is what makes results independent of which kernel a shape is routed to)."""
+    M, N, K = 1024, 768, 768
+    g = torch.Generator(device="cuda").manual_seed(7)
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g)
+    resid = torch.randn(M, N, device="cuda", generator=g)
+    for epi, dt in ((0, torch.bfloat16), (1, torch.bfloat16), (3, torch.float32)):
+        outs = []
+        for tile in (256, 128, 257, 258):
+            out = torch.empty(M, N, device="cuda", dtype=dt)
+            assert lib.gitcap_dbg_gemm(_p(A), _p(W), _p(bias), _p(resid), _p(out), M, N, K, epi, tile, _stream()) == 0
+            outs.append(out)
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o)
 
 
 @pytest.mark.parametrize("G,S,H", [(3, 197, 12), (2, 1182, 12), (4, 17, 2), (1, 64, 1), (2, 65, 3), (1, 257, 16)])
