@@ -254,9 +254,43 @@ class GitCaptioner(nn.Module):
                        ctypes.c_void_p(logits.data_ptr()), 1, None, 0, self._stream())
         return logits
 
-    def forward(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, y: Optional[torch.Tensor] = None):
+        """``forward(x, y)``: teacher-forced logits [B,T,V] (student signature, model.py:99-106).
+        ``forward(x)``: the teacher's form (``GenerativeImageTextTeacher.forward``, model.py:762-793)."""
+        if y is None:
+            return self.teacher_forward(x)
         _, memory = self.forward_image_enc(x)
         return self.forward_decoder(y, memory)
+
+    @torch.no_grad()
+    def teacher_forward(self, x: torch.Tensor, beam_size: int = 4, max_steps: int = 15) -> list:
+        """``GenerativeImageTextTeacher.forward`` (model.py:762-793): one dict per clip with the keys of
+        ``infer`` (model.py:456-461) plus ``cap`` (decoded caption, :770) and ``output`` [1, n, V] = for each of
+        the first n predicted words the logits of the beam that scores that word highest (:771-788).
+        The reference runs one clip at a time (:765); here all clips go through ONE batched search and only the
+        per-clip bookkeeping is a loop.  Without a tokenizer ``cap`` is None and n counts the tokens before SEP."""
+        res = self.infer(x, beam_size=beam_size, max_steps=max_steps, save_logits=True, on_device=False)
+        pred, logprobs, saved, vis = res["predictions"], res["logprobs"], res["logits_dict"], res["visual_features"]
+        out = []
+        for b in range(pred.shape[0]):
+            logits_b = [np.asarray(st[b * beam_size:(b + 1) * beam_size]) for st in saved]     # per step [beams, V]
+            ids = pred[b].tolist()
+            if self.tokenizer is not None:
+                cap = self.tokenizer.decode(ids, skip_special_tokens=True)
+                n = min(len(cap.split(" ")), len(logits_b))                                     # model.py:771
+            else:
+                cap = None
+                body = ids[1:]
+                n = min(body.index(self.sep_token_id) if self.sep_token_id in body else len(body), len(logits_b))
+            n = max(n, 1)
+            dist = torch.from_numpy(np.stack(logits_b[:n])).to(self._dev)                       # [n, beams, V]
+            words = pred[b, 1:n + 1].to(self._dev)
+            at_word = torch.gather(dist, 2, words[:, None, None].expand(-1, beam_size, -1)).squeeze(-1)   # [n, beams]
+            best = at_word.argmax(dim=1)                                                        # model.py:785
+            output = torch.gather(dist, 1, best[:, None, None].expand(-1, -1, dist.shape[-1])).squeeze(1)[None]
+            out.append({"predictions": pred[b:b + 1], "logprobs": logprobs[b:b + 1], "logits_dict": logits_b,
+                        "visual_features": vis[b:b + 1], "output": output, "cap": cap})
+        return out
 
     @torch.no_grad()
     def forward_output_logits(self, x: torch.Tensor, y: torch.Tensor):

@@ -310,3 +310,32 @@ def test_more_edge_inputs(captioner_cls):
     a2 = m2.greedy_decode(fr, max_len=8, stop="never").cpu()
     assert torch.equal(m.greedy_decode(fr, max_len=8, stop="never").cpu(), want)
     assert not torch.equal(a2, want)
+
+
+def test_teacher_forward_dicts(captioner_cls):
+    """GenerativeImageTextTeacher.forward (model.py:762-793): one dict per clip; 'output' = per predicted word
+    the logits of the beam scoring that word highest, restated here literally from :771-788."""
+    class SpaceTokenizer:                       # one "word" per token id, special ids dropped
+        def decode(self, ids, skip_special_tokens=True):
+            return " ".join(str(i) for i in ids if not (skip_special_tokens and i in (cfg.cls_token_id, cfg.sep_token_id, 0)))
+    cfg = git_tiny(2)
+    w = synthetic_weights(cfg, 0)
+    m = captioner_cls(cfg, w, max_batch=3, max_text_len=16, max_beams=4, tokenizer=SpaceTokenizer())
+    fr = make_frames(3, 2, cfg.image_size, 77)
+    outs = m(fr)                                # forward(x) without y = the teacher's form (beams 4, 15 steps: model.py:702-708)
+    assert isinstance(outs, list) and len(outs) == 3
+    for b, r in enumerate(outs):
+        assert set(r) == {"predictions", "logprobs", "logits_dict", "visual_features", "output", "cap"}
+        assert r["predictions"].shape[0] == 1 and r["visual_features"].shape[0] == 1
+        cap = r["cap"]
+        n = min(len(cap.split(" ")), len(r["logits_dict"]))
+        dist = torch.from_numpy(np.array(r["logits_dict"][:n]))                     # [n, 4, V]  (model.py:775)
+        word_tokens = r["predictions"][0, 1:n + 1].cpu()[:, None, None].expand(-1, 4, -1)
+        idx = torch.gather(dist, dim=2, index=word_tokens).squeeze(-1).argmax(dim=1)
+        want = torch.gather(dist, dim=1, index=idx[:, None, None].expand(-1, -1, dist.shape[-1])).squeeze(1)[None]
+        assert r["output"].shape == (1, n, cfg.vocab_size)
+        assert torch.equal(r["output"].cpu(), want)
+    # without a tokenizer: cap is None, n = tokens before SEP
+    m2 = captioner_cls(cfg, w, max_batch=3, max_text_len=12, max_beams=4)
+    r2 = m2.teacher_forward(fr, beam_size=4, max_steps=12)
+    assert r2[0]["cap"] is None and r2[0]["output"].shape[0] == 1 and r2[0]["output"].shape[2] == cfg.vocab_size
