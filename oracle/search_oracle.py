@@ -52,11 +52,36 @@ class BeamHypotheses:
         return self.worst_score >= best_sum_logprobs / self.max_length ** self.length_penalty
 
 
+def top_k_top_p_filtering(logits: torch.Tensor, top_k: int = 0, top_p: float = 1.0, filter_value: float = -float("inf"),
+                          min_tokens_to_keep: int = 1) -> torch.Tensor:
+    """The filter model.py:537 calls.  It lives in the absent ``generativeimage2text`` package (model.py:16),
+    which carries the published HF ``top_k_top_p_filtering``: keep the ``top_k`` largest logits (at least
+    ``min_tokens_to_keep``); then drop the tail of the descending-sorted distribution whose cumulative
+    probability exceeds ``top_p``, always keeping the first token that crosses it and at least
+    ``min_tokens_to_keep`` tokens."""
+    logits = logits.clone()
+    if top_k and top_k > 0:
+        top_k = min(max(top_k, min_tokens_to_keep), logits.size(-1))
+        logits[logits < torch.topk(logits, top_k)[0][..., -1, None]] = filter_value
+    if top_p is not None and top_p < 1.0:
+        sorted_logits, sorted_indices = torch.sort(logits, descending=True)
+        cumulative = torch.cumsum(F.softmax(sorted_logits, dim=-1), dim=-1)
+        remove = cumulative > top_p
+        if min_tokens_to_keep > 1:
+            remove[..., :min_tokens_to_keep] = False
+        remove[..., 1:] = remove[..., :-1].clone()
+        remove[..., 0] = False
+        logits[remove.scatter(-1, sorted_indices, remove)] = filter_value
+    return logits
+
+
 def beam_search(input_ids: torch.Tensor, step: Callable[[torch.Tensor], torch.Tensor], *, eos_index: int,
                 max_steps: int = 15, beam_size: int = 4, per_node_beam_size: int = 2,
-                length_penalty: float = 0.6, num_keep_best: int = 1):
-    """Greedy-beam branch of model.py:479-678 (do_sample=False, repetition_penalty=1, temperature=1).
-    ``step(ids[B*beams, cur_len]) -> logits[B*beams, V]`` of the last position (model.py:519).
+                length_penalty: float = 0.6, num_keep_best: int = 1, repetition_penalty: float = 1.0,
+                temperature: float = 1.0, do_sample: bool = False, top_k=None, top_p=None, generator=None):
+    """model.py:479-678: the greedy-beam branch (do_sample=False) and the sampling branch (:532-554), with the
+    repetition penalty of :522-531.  ``step(ids[B*beams, cur_len]) -> logits[B*beams, V]`` of the last position
+    (model.py:519).  ``generator`` seeds torch.multinomial (the reference uses the global RNG).
     Returns (decoded [B, max_steps] padded with EOS, logprobs [B, num_keep_best], saved_logits)."""
     batch_size, cur_len = input_ids.shape
     num_beams, pad_token_id = beam_size, eos_index
@@ -72,9 +97,29 @@ def beam_search(input_ids: torch.Tensor, step: Callable[[torch.Tensor], torch.Te
         scores = step(input_ids)
         vocab = scores.shape[-1]
         saved_logits.append(scores.detach().clone())
-        scores = F.log_softmax(scores.float(), dim=-1)                                 # :557
-        _scores = (scores + beam_scores[:, None]).view(batch_size, num_beams * vocab)  # :561-563
-        next_scores, next_words = torch.topk(_scores, per_node_beam_size * num_beams, dim=1, largest=True, sorted=True)
+        scores = scores.float().clone()
+        if repetition_penalty != 1.0:                                                  # :522-531
+            for i in range(batch_size * num_beams):
+                for previous_token in set(input_ids[i].tolist()):
+                    if scores[i, previous_token] < 0:
+                        scores[i, previous_token] *= repetition_penalty
+                    else:
+                        scores[i, previous_token] /= repetition_penalty
+        if do_sample:                                                                  # :532-554
+            if temperature != 1.0:
+                scores = scores / temperature
+            scores = top_k_top_p_filtering(scores, top_k=top_k or 0, top_p=1.0 if top_p is None else top_p, min_tokens_to_keep=2)
+            next_words = torch.multinomial(F.softmax(scores, dim=-1), num_samples=per_node_beam_size, generator=generator)
+            _scores = torch.gather(F.log_softmax(scores, dim=-1), -1, next_words)
+            next_scores = _scores + beam_scores[:, None].expand_as(_scores)
+            # (:549-552 as written: the beam offsets are TILED over the row while the samples are beam-major)
+            beam_indices = (torch.arange(num_beams) * vocab).repeat(batch_size, per_node_beam_size)
+            next_words = next_words.view(batch_size, per_node_beam_size * num_beams) + beam_indices
+            next_scores = next_scores.view(batch_size, per_node_beam_size * num_beams)
+        else:
+            scores = F.log_softmax(scores, dim=-1)                                     # :557
+            _scores = (scores + beam_scores[:, None]).view(batch_size, num_beams * vocab)  # :561-563
+            next_scores, next_words = torch.topk(_scores, per_node_beam_size * num_beams, dim=1, largest=True, sorted=True)
         next_batch_beam = []
         for b in range(batch_size):                                                    # :573
             done[b] = done[b] or hyps[b].is_done(next_scores[b].max().item())
@@ -92,8 +137,10 @@ def beam_search(input_ids: torch.Tensor, step: Callable[[torch.Tensor], torch.Te
                     break
             if cur_len + 1 == max_length:
                 assert len(next_sent_beam) == 0
-            else:
+            elif not do_sample:
                 assert len(next_sent_beam) == num_beams
+            elif 0 < len(next_sent_beam) < num_beams:      # sampling may draw EOS often: pad like a finished sentence
+                next_sent_beam += [(0, pad_token_id, 0)] * (num_beams - len(next_sent_beam))
             if len(next_sent_beam) == 0:
                 next_sent_beam = [(0, pad_token_id, 0)] * num_beams
             next_batch_beam.extend(next_sent_beam)

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle.search_oracle import beam_search as oracle_beam_search
+from oracle.search_oracle import top_k_top_p_filtering
 
 
 def _toy_step(V, seed):
@@ -85,6 +86,71 @@ def test_beam_topk_kernel_vs_torch():
         assert torch.equal(out_i.long(), ri)
     # argument errors are reported, not launched
     assert lib.gitcap_beam_topk(None, 1, None, 1, 1, 1, 1, None, None, None) == -1
+
+
+def test_oracle_top_k_top_p_filtering_known_answers():
+    """Published HF algorithm behind model.py:537: hand-worked cases."""
+    ninf = float("-inf")
+    p = torch.tensor([[0.5, 0.25, 0.15, 0.07, 0.03]])
+    lg = p.log()
+    # top_k=1 but min_tokens_to_keep=2 keeps the two largest
+    assert torch.equal(top_k_top_p_filtering(lg, top_k=1, min_tokens_to_keep=2) > ninf, torch.tensor([[True, True, False, False, False]]))
+    # top_p=0.7: cumulative 0.5, 0.75 -> the token that crosses 0.7 is kept, the rest dropped
+    assert torch.equal(top_k_top_p_filtering(lg, top_p=0.7) > ninf, torch.tensor([[True, True, False, False, False]]))
+    # top_p=0.95 keeps 0.5+0.25+0.15+0.07 (0.97 crosses), drops the last
+    assert torch.equal(top_k_top_p_filtering(lg, top_p=0.95) > ninf, torch.tensor([[True, True, True, True, False]]))
+    # order of the input does not matter; kept values are unchanged
+    perm = torch.tensor([3, 0, 4, 2, 1])
+    out = top_k_top_p_filtering(lg[:, perm], top_k=3)
+    assert torch.equal(out > ninf, torch.tensor([[False, True, False, True, True]])) and torch.equal(out[out > ninf], lg[:, perm][out > ninf])
+
+
+def test_oracle_sampling_branch_degenerate_cases():
+    """Sampling (model.py:532-554) with per_node_beam_size = 1 and a filter that leaves the two best tokens:
+    every drawn token is one of the step's two largest logits; repetition penalty 1.0 is the identity."""
+    V, eos, cls = 30, 29, 0
+    step = _toy_step(V, 4)
+    start = torch.tensor([[cls], [cls]])
+    g = torch.Generator().manual_seed(1)
+    dec, lp, _ = oracle_beam_search(start, step, eos_index=eos, max_steps=7, beam_size=2, per_node_beam_size=1,
+                                    do_sample=True, top_k=2, generator=g)
+    assert dec.shape == (2, 7) and bool((dec[:, 0] == cls).all())
+    for row in dec.tolist():
+        for t in range(1, len(row)):
+            if row[t] == eos:
+                break
+            top2 = step(torch.tensor([row[:t]]))[0].topk(2).indices.tolist()
+            assert row[t] in top2
+    a = oracle_beam_search(start, step, eos_index=eos, max_steps=7, beam_size=3)
+    b = oracle_beam_search(start, step, eos_index=eos, max_steps=7, beam_size=3, repetition_penalty=1.0, temperature=1.0)
+    assert torch.equal(a[0], b[0])
+    # the penalty rescales the logits of tokens already in the hypothesis (:522-531): the hypothesis scores change
+    c = oracle_beam_search(start, step, eos_index=eos, max_steps=7, beam_size=3, repetition_penalty=5.0)
+    assert c[0].shape == a[0].shape and not torch.allclose(c[1], a[1])
+
+
+@pytest.mark.gpu
+def test_product_sampling_and_repetition_penalty_vs_oracle():
+    """Same CPU generator on both sides: the product's vectorised device filtering + host draw must reproduce the
+    oracle's loop-style restatement of model.py:522-554 exactly on a toy step with well separated logits."""
+    from gitcap.search import GeneratorWithBeamSearch
+    V, eos, cls = 40, 39, 0
+    step_cpu = _toy_step(V, 11)
+    step_gpu = lambda ids: step_cpu(ids.cpu()).cuda()
+    start = torch.tensor([[cls], [cls], [cls]])
+    for kw in (dict(top_k=5), dict(top_p=0.8), dict(top_k=8, top_p=0.9)):
+        for rp, temp in ((1.0, 1.0), (1.3, 0.7)):
+            want = oracle_beam_search(start, step_cpu, eos_index=eos, max_steps=8, beam_size=3, length_penalty=0.6,
+                                      repetition_penalty=rp, temperature=temp, do_sample=True,
+                                      generator=torch.Generator().manual_seed(123), **kw)
+            got = GeneratorWithBeamSearch(eos, 8, 3, length_penalty=0.6, repetition_penalty=rp, temperature=temp).search(
+                start.cuda(), step_gpu, do_sample=True, generator=torch.Generator().manual_seed(123), **kw)
+            assert torch.equal(got[0].cpu(), want[0]), (kw, rp, temp)
+            assert torch.allclose(got[1].cpu(), want[1], atol=1e-4)
+    # repetition penalty on the greedy-beam branch (HIP top-k kernel on the penalised scores)
+    want = oracle_beam_search(start, step_cpu, eos_index=eos, max_steps=8, beam_size=4, length_penalty=0.6, repetition_penalty=1.5)
+    got = GeneratorWithBeamSearch(eos, 8, 4, length_penalty=0.6, repetition_penalty=1.5).search(start.cuda(), step_gpu)
+    assert torch.equal(got[0].cpu(), want[0]) and torch.allclose(got[1].cpu(), want[1], atol=1e-4)
 
 
 @pytest.mark.gpu
