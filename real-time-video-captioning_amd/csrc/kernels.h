@@ -40,6 +40,7 @@ struct SkinnyArgs {
     float* amax_val; int* amax_idx;    // SK_BIAS_F32 only (nullable): per-tile arg-max partials [M][ntiles]
 };
 hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s);
+bool skinny_full_ok(int K);                                  // K depths launch_skinny is instantiated for
 int skinny_ksplit(int K);                                    // number of K slabs launch_skinny_splitk writes
 hipError_t launch_skinny_splitk(const SkinnyArgs& a, hipStream_t s);
 // x = LayerNorm(sum_s slab[s][m][:] + bias + resid[m][:]) -> xf (fp32) and xb (bf16); one wave per row

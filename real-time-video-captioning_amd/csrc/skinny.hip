@@ -145,6 +145,11 @@ hipError_t launch_full(const SkinnyArgs& a, int epi, hipStream_t s) {
 
 }  // namespace
 
+bool skinny_full_ok(int K) {
+    const int k32 = K / 32;
+    return K % 32 == 0 && (k32 == 2 || k32 == 4 || k32 == 8 || k32 == 18 || k32 == 24 || k32 == 32);
+}
+
 hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s) {
     if (a.K % 32 || a.M <= 0 || a.T <= 0) return hipErrorInvalidValue;
     switch (a.K / 32) {

@@ -287,7 +287,8 @@ int gitcap_student_create(const gitcap_student_config* cfg, int device, gitcap_s
         return sfail(nullptr, GITCAP_ERR_ARG, "student_create: d_model/d_ffn must be multiples of 32, d_model <= 1024 and divisible by n_head");
     const int hd = c.d_model / c.n_head;
     if (hd % 8 || hd > 128) return sfail(nullptr, GITCAP_ERR_ARG, "student_create: head_dim must be a multiple of 8, <= 128");
-    if (!skinny_ksplit(c.d_model) || !skinny_ksplit(c.d_ffn)) return sfail(nullptr, GITCAP_ERR_ARG, "student_create: unsupported d_model/d_ffn for the split-K kernels");
+    if (!skinny_full_ok(c.d_model) || !skinny_ksplit(c.d_model) || !skinny_ksplit(c.d_ffn))
+        return sfail(nullptr, GITCAP_ERR_ARG, "student_create: no skinny-GEMM instantiation for this d_model / d_ffn (d_model in {64,128,256,576,768,1024})");
     if (c.num_layers <= 0 || c.vocab_size <= 0 || c.mem_tokens <= 0 || c.mem_tokens > 64 || c.max_rows <= 0)
         return sfail(nullptr, GITCAP_ERR_ARG, "student_create: bad layer / vocabulary / memory sizes (mem_tokens <= 64)");
     if (c.max_text_len <= 0 || c.max_text_len + 1 > 64 || c.max_text_len + 1 > c.max_pos)

@@ -205,6 +205,9 @@ def test_gpu_stop_rule_pickle_and_errors():
         m.greedy_decode(torch.zeros(2, 6, 3, 32, 32), max_len=4)   # frames without an image_encoder
     with pytest.raises(GitcapError):
         m.to("cpu")
+    from gitcap.student import StudentCaptioner
+    with pytest.raises(GitcapError, match="d_model"):
+        StudentCaptioner(d_model=512, n_head=8, d_ffn=1024)             # no kernel instantiation: refused at create
     sd = {k: v for k, v in m.state_dict().items() if k != "pos_enc.pe"}
     sd["image_encoder.model.stem.weight"] = torch.zeros(1)          # foreign keys of a reference checkpoint are ignored
     m.load_state_dict(sd)                                           # pos_enc.pe rebuilt from the formula
