@@ -99,6 +99,17 @@ std::string g_create_err;
 // persistent-tile GEMM (gemm256p.hip) is an opt-in experiment: +2-5 % on multi-round shapes, slower on
 // the fp32-residual epilogue (DESIGN.md "What did not work")
 const bool g_persist = getenv("GITCAP_GEMM_PERSIST") && atoi(getenv("GITCAP_GEMM_PERSIST")) != 0;
+// 256x256-tile count below which the 128x128 kernel is used (GITCAP_GEMM_SMALL_TILES=0 disables the switch)
+const int g_small_tiles = getenv("GITCAP_GEMM_SMALL_TILES") ? atoi(getenv("GITCAP_GEMM_SMALL_TILES")) : 128;
+
+// Tile kernel selection.  Few 256x256 tiles (small batches: one 6-frame clip is 5 x 3..12 tiles for 256 CUs) leave
+// most of the chip idle: below g_small_tiles tiles the 128x128 kernel (4x the workgroups, two per CU) is used
+// (B=1: 7.7 -> 6.8 ms per caption).  All tile kernels produce bitwise identical results
+// (tests/test_kernels_gpu.py), so the choice only affects speed.
+hipError_t launch_gemm_auto(const GemmArgs& a, int epi, hipStream_t s) {
+    if (!gemm256_ok(a) || (a.M >> 8) * (a.N >> 8) < g_small_tiles) return launch_gemm(a, epi, s);
+    return g_persist ? launch_gemm256p(a, epi, s) : launch_gemm256(a, epi, s);
+}
 
 int fail(const gitcap* h, int code, const std::string& msg) {
     if (h) h->err = msg; else g_create_err = msg;
@@ -208,7 +219,7 @@ int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const bf16
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
     a.resid = resid; a.ldr = ldr;
-    HIP_OK(h, gemm256_ok(a) ? (g_persist ? launch_gemm256p(a, epi, s) : launch_gemm256(a, epi, s)) : launch_gemm(a, epi, s));
+    HIP_OK(h, launch_gemm_auto(a, epi, s));
     return 0;
 }
 
@@ -551,7 +562,7 @@ static int encode_impl(gitcap* h, const float* frames, int B, int F, float* visu
         GemmArgs a{};
         a.A = h->patches; a.lda = h->Kp; a.W = h->patch_w; a.bias = nullptr; a.M = Pp; a.N = Dv; a.K = h->Kp;
         a.out = h->x; a.ldo = Dv; a.pos = h->pos; a.tokens_per_frame = N; a.patches_per_frame = h->G * h->G; a.valid_rows = P;
-        HIP_OK(h, gemm256_ok(a) ? (g_persist ? launch_gemm256p(a, EPI_PATCH_F32, s) : launch_gemm256(a, EPI_PATCH_F32, s)) : launch_gemm(a, EPI_PATCH_F32, s));
+        HIP_OK(h, launch_gemm_auto(a, EPI_PATCH_F32, s));
     }
     HIP_OK(h, launch_cls_rows(h->x, h->cls, h->pos, nf, N, Dv, s));
     h->prof_rows = rows;
