@@ -4,6 +4,7 @@
 #include "kernels.h"
 #include "host_util.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -84,6 +85,8 @@ struct gitcap {
     Slot slots[NSLOT];
     int cur_slot = 0, next_ticket = 0;
     hipStream_t s_enc = nullptr;
+    hipStream_t txt_streams[NSLOT] = {nullptr, nullptr, nullptr, nullptr};   // owned; slot i decodes on txt_streams[i % n_txt]
+    int n_txt = NSLOT;
     double prof_rows = 0;   // valid rows of the GEMMs being launched (set by the callers of gemm())
 
     // instrumentation (bench.py): HIP-event brackets per kernel class, on the launch stream
@@ -99,6 +102,13 @@ std::string g_create_err;
 // persistent-tile GEMM (gemm256p.hip) is an opt-in experiment: +2-5 % on multi-round shapes, slower on
 // the fp32-residual epilogue (DESIGN.md "What did not work")
 const bool g_persist = getenv("GITCAP_GEMM_PERSIST") && atoi(getenv("GITCAP_GEMM_PERSIST")) != 0;
+// Number of decode streams the four slots share (slot i decodes on stream i % n).  HIP multiplexes streams onto
+// GPU_MAX_HW_QUEUES (default 4) hardware queues; with one stream per slot the throughput depended on which streams
+// happened to share a queue (1073-1723 captions/s over 1..8 queues, 1514 as soon as an RCCL communicator added its
+// streams).  Two decode streams + the image-pass stream + the caller's stream fit the four queues: 1743 captions/s
+// with or without RCCL.  One stream is too few: a token loop runs ~2x slower next to the GEMMs and must overlap
+// another one to keep up with the image pass.
+const int g_txt_streams = getenv("GITCAP_TXT_STREAMS") ? std::max(1, std::min(4, atoi(getenv("GITCAP_TXT_STREAMS")))) : 2;
 // 256x256-tile count below which the 128x128 kernel is used (GITCAP_GEMM_SMALL_TILES=0 disables the switch)
 const int g_small_tiles = getenv("GITCAP_GEMM_SMALL_TILES") ? atoi(getenv("GITCAP_GEMM_SMALL_TILES")) : 128;
 
@@ -435,8 +445,11 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
         // plain non-blocking streams for the pipeline (stream priorities measured neutral and
         // CU-masked streams 2.5x slower on this platform: DESIGN.md "What did not work")
         bool ok = hipStreamCreateWithFlags(&h->s_enc, hipStreamNonBlocking) == hipSuccess;
+        h->n_txt = g_txt_streams;
+        for (int i = 0; i < h->n_txt; ++i) ok = ok && hipStreamCreateWithFlags(&h->txt_streams[i], hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < gitcap::NSLOT; ++i) h->slots[i].s_txt = h->txt_streams[i % h->n_txt];
         for (auto& sl : h->slots)
-            ok = ok && hipStreamCreateWithFlags(&sl.s_txt, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming) == hipSuccess &&
+            ok = ok && hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&sl.ev_enc, hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&sl.ev_dec, hipEventDisableTiming) == hipSuccess;
         if (!ok) rc = fail(h, GITCAP_ERR_HIP, "create: stream/event creation failed");
@@ -466,8 +479,9 @@ void gitcap_destroy(gitcap_t* h) {
         if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
         if (sl.ev_enc) (void)hipEventDestroy(sl.ev_enc);
         if (sl.ev_dec) (void)hipEventDestroy(sl.ev_dec);
-        if (sl.s_txt) (void)hipStreamDestroy(sl.s_txt);
     }
+    for (auto& t : h->txt_streams)
+        if (t) (void)hipStreamDestroy(t);
     if (h->s_enc) (void)hipStreamDestroy(h->s_enc);
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto& kv : h->w)
