@@ -58,3 +58,41 @@ def test_bad_config_is_rejected_before_touching_the_device():
     assert lib.gitcap_create(ctypes.byref(cc), 0, ctypes.byref(h)) == -1
     assert b"head_dim" in lib.gitcap_last_error(None)
     assert lib.gitcap_create(None, 0, ctypes.byref(h)) == -1
+
+
+def _struct_fields(name):
+    """Field names of `struct <name> { ... };` in include/gitcap.h, in declaration order."""
+    txt = open(os.path.join(ROOT, "include", "gitcap.h")).read()
+    body = re.search(r"struct\s+%s\s*\{(.*?)\}\s*\w*\s*;" % name, txt, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            out += [f.strip() for f in decl.split(None, 1)[1].split(",")]
+    return out
+
+
+def test_ctypes_structs_mirror_the_header_field_order():
+    from gitcap.student_config import CStudentConfig
+    assert [f for f, _ in CStudentConfig._fields_] == _struct_fields("gitcap_student_config")
+    assert [f for f, _ in CGitCapConfig._fields_] == _struct_fields("gitcap_config")
+
+
+def test_student_abi_rejects_bad_configs_and_has_no_cpu_path():
+    from gitcap.student_config import CStudentConfig, StudentConfig, student_tiny
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    bad = CStudentConfig.from_config(StudentConfig(d_model=512, n_head=8, d_ffn=1024), 4, 16)     # no kernel instantiation
+    assert lib.gitcap_student_create(ctypes.byref(bad), 0, ctypes.byref(h)) == -1 and not h
+    assert b"d_model" in lib.gitcap_student_last_error(None)
+    long_ = CStudentConfig.from_config(student_tiny(), 4, 64)                                        # > 63 tokens
+    assert lib.gitcap_student_create(ctypes.byref(long_), 0, ctypes.byref(h)) == -1
+    assert lib.gitcap_student_create(None, 0, ctypes.byref(h)) == -1
+    if not torch.cuda.is_available():
+        ok = CStudentConfig.from_config(student_tiny(), 4, 16)
+        assert lib.gitcap_student_create(ctypes.byref(ok), 0, ctypes.byref(h)) < 0 and not h
+        assert b"no CPU fallback" in lib.gitcap_student_last_error(None)
+        from gitcap.student import StudentCaptioner
+        with pytest.raises(_lib.GitcapError):
+            StudentCaptioner(cfg=student_tiny())
