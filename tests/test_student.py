@@ -237,3 +237,22 @@ def test_gpu_beam_search(golden_dir):
     assert (got == torch.from_numpy(g["beam_k3"])).float().mean().item() > 0.8
     with pytest.raises(ValueError):
         m.beam_search(make_memory(5, cfg.mem_tokens, cfg.d_model, 1), max_len=5, k=3)      # 15 rows > max_batch
+
+
+@pytest.mark.gpu
+def test_gpu_student_batch_invariance_and_determinism():
+    """Every kernel on the path sums in an order that depends only on the row itself: a clip must decode to
+    bit-identical logits and ids alone, inside a batch of 5, and on a repeated call (graph replay included)."""
+    cfg = student_base()
+    w = student_synthetic_weights(cfg, 0)
+    m = _student(cfg, w, max_batch=8, max_text_len=25)
+    mem = make_memory(5, cfg.mem_tokens, cfg.d_model, 31)
+    ids = m.greedy_decode(mem, max_len=25, stop="never")
+    assert torch.equal(ids, m.greedy_decode(mem, max_len=25, stop="never"))          # replayed graph
+    full = m.forward_decoder(ids[:, :-1], mem)
+    for b in (0, 3, 4):
+        assert torch.equal(m.greedy_decode(mem[b:b + 1], max_len=25, stop="never"), ids[b:b + 1])
+        assert torch.equal(m.forward_decoder(ids[b:b + 1, :-1], mem[b:b + 1]), full[b:b + 1])
+    # a permutation of the batch permutes the result
+    perm = torch.tensor([3, 0, 4, 1, 2])
+    assert torch.equal(m.greedy_decode(mem[perm], max_len=25, stop="never"), ids[perm])
