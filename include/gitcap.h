@@ -144,7 +144,7 @@ int gitcap_beam_search(gitcap_t* h, const float* frames, int B, int F, int beams
 
 /* Pipelined form of gitcap_greedy for a stream of batches (no reference counterpart: the reference
  * processes one clip at a time, src/models/model.py:765).  submit enqueues the image pass on the
- * handle's encoder stream and the text loop on its decoder stream, ordered after the work already
+ * handle's encoder stream and the text loop on one of its two decoder streams, ordered after the work already
  * on `stream` (so `frames` may be produced there), and returns a ticket; at most FOUR submissions
  * may be in flight (four slots), so one batch's MFMA-bound image pass overlaps the latency-bound
  * token loops of the batches before it.  wait makes `stream` wait for that submission's ids_out/steps_out.

@@ -67,14 +67,14 @@ struct gitcap {
     int cur_B = 0, cur_S = 0;
     bool have_image = false;
 
-    // Four slots (image-prefix K/V, text-row workspace, stop counters, decode stream).  While one
+    // Four slots (image-prefix K/V, text-row workspace, stop counters; two decode streams shared by the slots).  While one
     // batch's image pass (MFMA bound) runs on `s_enc`, the token loops of the batches submitted before
-    // it (chains of tiny latency-bound kernels) interleave on their slots' own streams
+    // it (chains of tiny latency-bound kernels) interleave on the decode streams (slot i on stream i % n_txt)
     // (gitcap_greedy_submit / _wait).  The synchronous entry points always use slot 0 on the caller's
     // stream; do not mix them with submissions that are still in flight.
     struct Slot {
         bf16_t* kv_img = nullptr; int32_t* sep_cnt = nullptr;
-        // text-row workspace of the slot (each slot's token loop runs on its own stream)
+        // text-row workspace of the slot (token loops of different slots may run concurrently)
         float *xs = nullptr, *slabs = nullptr, *amax_val = nullptr; int* amax_idx = nullptr;
         bf16_t *xsb = nullptr, *cs = nullptr, *fs = nullptr, *kv_txt = nullptr, *kv_txt2 = nullptr;
         int B = 0, S = 0; bool have = false, used = false;
