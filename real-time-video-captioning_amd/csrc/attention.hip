@@ -14,9 +14,7 @@
 //                 256-B bank row exactly once.
 //   Both are filled by LDS-DMA (global_load_lds_dwordx4), double buffered, one barrier per tile.
 //
-// attn_text_kernel: text rows (prefill with T tokens or one decode step).  HBM-bound K/V
-//   streaming straight to VGPRs, 8 lanes per key row (16 B each), per-8-lane-group online softmax
-//   state so the inner loop has no cross-group traffic; groups and waves are merged at the end.
+// (The attention of the TEXT rows -- decode steps and teacher-forced prefixes -- is in txtblock.hip.)
 #include "kernels.h"
 #include <cstdlib>
 
@@ -228,137 +226,6 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// text rows
-// ------------------------------------------------------------------------------------------
-struct Part { float m, l; float o[8]; };
-
-__device__ __forceinline__ void merge(Part& a, float m2, float l2, const float* o2) {
-    const float M = fmaxf(a.m, m2);
-    const float s1 = (a.m == -INFINITY) ? 0.f : fast_exp2(a.m - M);
-    const float s2 = (m2 == -INFINITY) ? 0.f : fast_exp2(m2 - M);
-    a.l = a.l * s1 + l2 * s2;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) a.o[d] = a.o[d] * s1 + o2[d] * s2;
-    a.m = M;
-}
-
-// One 16-wave workgroup per (text row m, head).  Wave w takes the 32-key groups w, w+16, ... : the
-// partition (and therefore the summation order) depends only on the key count, never on the batch
-// size, so a clip decodes to bitwise the same logits alone or inside any batch.
-__global__ __launch_bounds__(1024) void attn_text_kernel(TextAttnArgs a) {
-    __shared__ float wsm[16][8][10];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = blockIdx.x, head = blockIdx.y;
-    const int r = m / a.T, j = m - r * a.T;
-    const int clip = r / a.beams;
-    const int D = a.D, ld = 3 * D;
-    const int tq = a.t0 + j;
-    const int Lk = a.S_img + tq + 1;
-    const int sub = lane & 7, kk = lane >> 3;
-
-    const bf16_t* img = a.kv_img + (size_t)clip * a.S_img * ld + D + head * 64 + sub * 8;
-    const bf16_t* txt = a.kv_txt + (size_t)r * a.Tmax * ld + D + head * 64 + sub * 8;
-
-    float qv[8];
-    {
-        const bf16x8 q8 = *(const bf16x8*)(a.kv_txt + ((size_t)r * a.Tmax + tq) * ld + head * 64 + sub * 8);
-#pragma unroll
-        for (int d = 0; d < 8; ++d) qv[d] = bf2f((bf16_t)q8[d]) * kScaleLog2e;
-    }
-    Part st;
-    st.m = -INFINITY; st.l = 0.f;
-#pragma unroll
-    for (int d = 0; d < 8; ++d) st.o[d] = 0.f;
-
-    // Each wave owns only 2-3 groups of 32 keys, so the K/V load latency would be fully exposed:
-    // the loads of group i+1 are issued before group i is reduced (two register sets, static names).
-    auto load_group = [&](int g0, bf16x8* kf, bf16x8* vf, bool* valid) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int key = g0 + u * 8 + kk;
-            valid[u] = key < Lk;
-            key = valid[u] ? key : 0;
-            const bf16_t* kp = key < a.S_img ? img + (size_t)key * ld : txt + (size_t)(key - a.S_img) * ld;
-            kf[u] = *(const bf16x8*)kp;
-            vf[u] = *(const bf16x8*)(kp + D);
-        }
-    };
-    auto reduce_group = [&](const bf16x8* kf, const bf16x8* vf, const bool* valid) {
-        float sc[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) s += qv[d] * bf2f((bf16_t)kf[u][d]);
-            s += __shfl_xor(s, 1);
-            s += __shfl_xor(s, 2);
-            s += __shfl_xor(s, 4);
-            sc[u] = valid[u] ? s : -INFINITY;
-        }
-        const float mt = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-        const float m_new = fmaxf(st.m, mt);
-        if (m_new != -INFINITY) {
-            const float alpha = (st.m == -INFINITY) ? 0.f : fast_exp2(st.m - m_new);
-            st.l *= alpha;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) st.o[d] *= alpha;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float p = fast_exp2(sc[u] - m_new);       // exp2(-inf) = 0 for masked keys
-                st.l += p;
-                const float pb = bf2f(f2bf(p));                 // P enters the PV product as bf16 (same rule as the MFMA path)
-#pragma unroll
-                for (int d = 0; d < 8; ++d) st.o[d] += pb * bf2f((bf16_t)vf[u][d]);
-            }
-            st.m = m_new;
-        }
-    };
-    {
-        bf16x8 kA[4], vA[4], kB[4], vB[4];
-        bool okA[4], okB[4];
-        int g0 = wid * 32;
-        if (g0 < Lk) load_group(g0, kA, vA, okA);
-        while (g0 < Lk) {
-            if (g0 + 512 < Lk) load_group(g0 + 512, kB, vB, okB);
-            reduce_group(kA, vA, okA);
-            g0 += 512;
-            if (g0 >= Lk) break;
-            if (g0 + 512 < Lk) load_group(g0 + 512, kA, vA, okA);
-            reduce_group(kB, vB, okB);
-            g0 += 512;
-        }
-    }
-    // merge the 8 key-groups of the wave (lanes with equal sub)
-#pragma unroll
-    for (int off = 8; off < 64; off <<= 1) {
-        const float m2 = __shfl_xor(st.m, off), l2 = __shfl_xor(st.l, off);
-        float o2[8];
-#pragma unroll
-        for (int d = 0; d < 8; ++d) o2[d] = __shfl_xor(st.o[d], off);
-        merge(st, m2, l2, o2);
-    }
-    if (kk == 0) {
-        wsm[wid][sub][0] = st.m; wsm[wid][sub][1] = st.l;
-#pragma unroll
-        for (int d = 0; d < 8; ++d) wsm[wid][sub][2 + d] = st.o[d];
-    }
-    __syncthreads();
-    if (tid < 8) {
-        Part t;
-        t.m = wsm[0][tid][0]; t.l = wsm[0][tid][1];
-#pragma unroll
-        for (int d = 0; d < 8; ++d) t.o[d] = wsm[0][tid][2 + d];
-        for (int w = 1; w < 16; ++w) merge(t, wsm[w][tid][0], wsm[w][tid][1], &wsm[w][tid][2]);
-        const float inv = 1.0f / t.l;
-        uint4 v;
-        v.x = pack_bf2(t.o[0] * inv, t.o[1] * inv); v.y = pack_bf2(t.o[2] * inv, t.o[3] * inv);
-        v.z = pack_bf2(t.o[4] * inv, t.o[5] * inv); v.w = pack_bf2(t.o[6] * inv, t.o[7] * inv);
-        *(uint4*)(a.ctx + (size_t)m * D + head * 64 + tid * 8) = v;
-    }
-}
-
 }  // namespace
 
 hipError_t launch_attn_full(const bf16_t* qkv, bf16_t* ctx, int G, int S, int H, hipStream_t s) {
@@ -369,12 +236,5 @@ hipError_t launch_attn_full(const bf16_t* qkv, bf16_t* ctx, int G, int S, int H,
     if (nst == 2) hipLaunchKernelGGL(attn_full_kernel<2>, grid, dim3(256), 0, s, qkv, ctx, S, H, G, nqb);
     else if (nst == 4) hipLaunchKernelGGL(attn_full_kernel<4>, grid, dim3(256), 0, s, qkv, ctx, S, H, G, nqb);
     else hipLaunchKernelGGL(attn_full_kernel<3>, grid, dim3(256), 0, s, qkv, ctx, S, H, G, nqb);
-    return hipGetLastError();
-}
-
-hipError_t launch_attn_text(const TextAttnArgs& a, hipStream_t s) {
-    const int M = a.rows * a.T;
-    if (M <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_text_kernel, dim3(M, a.H), dim3(1024), 0, s, a);
     return hipGetLastError();
 }

@@ -45,9 +45,10 @@ struct gitcap {
     float *x = nullptr, *tmp = nullptr;
     bf16_t *hb = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr, *patches = nullptr, *kv_img = nullptr;
     // workspace (text rows)
-    float *xs = nullptr, *slabs = nullptr, *amax_val = nullptr;
+    float *xs = nullptr, *slabs = nullptr, *part = nullptr, *amax_val = nullptr;
     int* amax_idx = nullptr;
-    bf16_t *xsb = nullptr, *cs = nullptr, *fs = nullptr, *kv_txt = nullptr, *kv_txt2 = nullptr;
+    unsigned* row_cnt = nullptr;
+    bf16_t *xsb = nullptr, *fs = nullptr, *kv_txt = nullptr, *kv_txt2 = nullptr;
     int32_t* sep_cnt = nullptr;
     BeamBuffers beam{};                 // device-resident beam-search state (gitcap_beam_search)
     float* beam_logits = nullptr;       // [R][V]
@@ -75,8 +76,9 @@ struct gitcap {
     struct Slot {
         bf16_t* kv_img = nullptr; int32_t* sep_cnt = nullptr;
         // text-row workspace of the slot (token loops of different slots may run concurrently)
-        float *xs = nullptr, *slabs = nullptr, *amax_val = nullptr; int* amax_idx = nullptr;
-        bf16_t *xsb = nullptr, *cs = nullptr, *fs = nullptr, *kv_txt = nullptr, *kv_txt2 = nullptr;
+        float *xs = nullptr, *slabs = nullptr, *part = nullptr, *amax_val = nullptr; int* amax_idx = nullptr;
+        unsigned* row_cnt = nullptr;
+        bf16_t *xsb = nullptr, *fs = nullptr, *kv_txt = nullptr, *kv_txt2 = nullptr;
         int B = 0, S = 0; bool have = false, used = false;
         hipEvent_t ev_in = nullptr, ev_enc = nullptr, ev_dec = nullptr;
         hipStream_t s_txt = nullptr;
@@ -132,8 +134,8 @@ void select_slot(gitcap* h, int i) {
     o.kv_txt = h->kv_txt; o.kv_txt2 = h->kv_txt2;        // reorder_rows swaps these two
     gitcap::Slot& n = h->slots[i];
     h->kv_img = n.kv_img; h->sep_cnt = n.sep_cnt; h->cur_B = n.B; h->cur_S = n.S; h->have_image = n.have;
-    h->xs = n.xs; h->slabs = n.slabs; h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
-    h->xsb = n.xsb; h->cs = n.cs; h->fs = n.fs; h->kv_txt = n.kv_txt; h->kv_txt2 = n.kv_txt2;
+    h->xs = n.xs; h->slabs = n.slabs; h->part = n.part; h->row_cnt = n.row_cnt; h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
+    h->xsb = n.xsb; h->fs = n.fs; h->kv_txt = n.kv_txt; h->kv_txt2 = n.kv_txt2;
     h->cur_slot = i;
 }
 
@@ -300,27 +302,39 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     if (t0 + T > c.max_text_pos) return fail(h, GITCAP_ERR_ARG, "text_forward: position exceeds max_text_pos");
     const int D = h->D, M = rows * T, H = c.dec_heads;
     int rc;
-    HIP_OK(h, launch_embed_text(ids, ld_ids, rows, T, t0, h->word, h->tpos, h->txt_lnw, h->txt_lnb, c.dec_ln_eps, D,
-                                c.vocab_size, h->xs, h->xsb, s));
     const size_t kvi_layer = (size_t)h->Mi * 3 * D, kvt_layer = (size_t)h->R * h->Tmax * 3 * D;
-    const int ks_d = skinny_ksplit(D), ks_f = skinny_ksplit(c.dec_ffn);
+    const int ks_f = skinny_ksplit(c.dec_ffn);
+    // Per layer 5 launches: [text embedding | reduce of the previous layer's FC2 slabs + LayerNorm], q|k|v projection
+    // straight into the text K/V cache, attention + output dense + LayerNorm (txtblock.hip), FC1 + GELU, FC2 as split-K
+    // partial slabs.
     for (int l = 0; l < c.dec_layers; ++l) {
         const DecLayer& L = h->dec[l];
         bf16_t* kvt = h->kv_txt + (size_t)l * kvt_layer;
+        if (l == 0) {
+            HIP_OK(h, launch_embed_text(ids, ld_ids, rows, T, t0, h->word, h->tpos, h->txt_lnw, h->txt_lnb, c.dec_ln_eps, D,
+                                        c.vocab_size, h->xs, h->xsb, s));
+        } else {
+            const DecLayer& P = h->dec[l - 1];
+            if ((rc = ln_reduce(h, s, h->slabs, ks_f, P.fc2b, h->xs, P.ln2w, P.ln2b, c.dec_ln_eps, M, D, h->xs, h->xsb))) return rc;
+        }
         if ((rc = skinny(h, s, SK_BIAS_BF16, h->xsb, D, L.qkvw, L.qkvb, M, 3 * D, D, kvt, 3 * D, T, h->Tmax, t0))) return rc;
         {
+            TxtBlockArgs ta{};
+            ta.kv_img = h->kv_img + (size_t)l * kvi_layer; ta.kv_txt = kvt;
+            ta.rows = rows; ta.beams = beams; ta.t0 = t0; ta.T = T; ta.Tmax = h->Tmax; ta.S_img = h->cur_S; ta.H = H; ta.D = D;
+            ta.aow = L.aow; ta.aob = L.aob; ta.g1 = L.ln1w; ta.b1 = L.ln1b; ta.xin = h->xs; ta.eps = c.dec_ln_eps;
+            ta.part = h->part; ta.cnt = h->row_cnt; ta.xs = h->xs; ta.xsb = h->xsb;
             double kvb = 0;
             for (int j = 0; j < T; ++j) kvb += (double)rows * (h->cur_S + t0 + j + 1) * 2 * D * 2;
-            ProfScope ps(h, GITCAP_PROF_ATTN_TEXT, s, 0.0, kvb);
-            TextAttnArgs ta{h->kv_img + (size_t)l * kvi_layer, kvt, h->cs, rows, beams, t0, T, h->Tmax, h->cur_S, H, D};
-            HIP_OK(h, launch_attn_text(ta, s));
+            ProfScope ps(h, GITCAP_PROF_ATTN_TEXT, s, 0.0, kvb + 2.0 * D * D);     // K/V read once + the output dense
+            HIP_OK(h, launch_txt_block(ta, s));
         }
-        // attention output dense: split-K partial slabs, then sum + bias + residual + LayerNorm in one row kernel
-        if ((rc = skinny_splitk(h, s, h->cs, D, L.aow, M, D, D, h->slabs))) return rc;
-        if ((rc = ln_reduce(h, s, h->slabs, ks_d, L.aob, h->xs, L.ln1w, L.ln1b, c.dec_ln_eps, M, D, h->xs, h->xsb))) return rc;
         if ((rc = skinny(h, s, SK_BIAS_GELU_BF16, h->xsb, D, L.fc1w, L.fc1b, M, c.dec_ffn, D, h->fs, c.dec_ffn))) return rc;
         if ((rc = skinny_splitk(h, s, h->fs, c.dec_ffn, L.fc2w, M, D, c.dec_ffn, h->slabs))) return rc;
-        if ((rc = ln_reduce(h, s, h->slabs, ks_f, L.fc2b, h->xs, L.ln2w, L.ln2b, c.dec_ln_eps, M, D, h->xs, h->xsb))) return rc;
+    }
+    {   // the last layer's FC2 reduce + bias + residual + LayerNorm
+        const DecLayer& P = h->dec[c.dec_layers - 1];
+        if ((rc = ln_reduce(h, s, h->slabs, ks_f, P.fc2b, h->xs, P.ln2w, P.ln2b, c.dec_ln_eps, M, D, h->xs, h->xsb))) return rc;
     }
     if (!logits_out && !argmax_out) return 0;
     // vocabulary head (+ arg-max partials per 16-column tile, reduced by argmax_final)
@@ -373,7 +387,8 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
         return fail(nullptr, GITCAP_ERR_ARG, "create: head_dim must be 64");
     for (int n : {c.enc_width, c.enc_ffn, c.dec_width, c.dec_ffn})
         if (n % 128) return fail(nullptr, GITCAP_ERR_ARG, "create: widths must be multiples of 128");
-    if (c.enc_width > 1024 || c.dec_width > 1024) return fail(nullptr, GITCAP_ERR_ARG, "create: width > 1024 unsupported");
+    if (c.enc_width > 1024) return fail(nullptr, GITCAP_ERR_ARG, "create: enc_width > 1024 unsupported");
+    if (!txt_block_ok(c.dec_width)) return fail(nullptr, GITCAP_ERR_ARG, "create: dec_width must be 768 (GIT) or 128 (test config)");
     if (c.max_batch <= 0 || c.max_frames <= 0 || c.max_text_len <= 0 || c.max_beams <= 0)
         return fail(nullptr, GITCAP_ERR_ARG, "create: max_* must be positive");
     if (c.patch_size % 2) return fail(nullptr, GITCAP_ERR_ARG, "create: odd patch_size unsupported");
@@ -414,7 +429,8 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
         rc = rc ? rc : ws_alloc(h, &sl.xs, Mt * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.slabs, (size_t)16 * Mt * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.xsb, Mt * h->D);
-        rc = rc ? rc : ws_alloc(h, &sl.cs, Mt * h->D);
+        rc = rc ? rc : ws_alloc(h, &sl.part, Mt * (size_t)c.dec_heads * h->D);
+        rc = rc ? rc : ws_alloc(h, &sl.row_cnt, Mt);
         rc = rc ? rc : ws_alloc(h, &sl.fs, Mt * c.dec_ffn);
         rc = rc ? rc : ws_alloc(h, &sl.amax_val, Mt * (size_t)((h->V + 15) / 16));
         rc = rc ? rc : ws_alloc(h, &sl.amax_idx, Mt * (size_t)((h->V + 15) / 16));
@@ -438,8 +454,9 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     }
     if (!rc) {   // select slot 0
         gitcap::Slot& n = h->slots[0];
-        h->sep_cnt = n.sep_cnt; h->xs = n.xs; h->slabs = n.slabs; h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
-        h->xsb = n.xsb; h->cs = n.cs; h->fs = n.fs; h->kv_txt = n.kv_txt; h->kv_txt2 = n.kv_txt2;
+        h->sep_cnt = n.sep_cnt; h->xs = n.xs; h->slabs = n.slabs; h->part = n.part; h->row_cnt = n.row_cnt;
+        h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
+        h->xsb = n.xsb; h->fs = n.fs; h->kv_txt = n.kv_txt; h->kv_txt2 = n.kv_txt2;
     }
     if (!rc) {
         // plain non-blocking streams for the pipeline (stream priorities measured neutral and

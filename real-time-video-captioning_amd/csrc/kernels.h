@@ -57,14 +57,23 @@ hipError_t launch_argmax_final(const float* amax_val, const int* amax_idx, int n
 // prefix of the decoder (S = F*N).
 hipError_t launch_attn_full(const bf16_t* qkv, bf16_t* ctx, int G, int S, int H, hipStream_t s);
 
-// Text rows: query (r, t0+j) attends image keys of clip r/beams and text keys 0..t0+j of row r.
-struct TextAttnArgs {
-    const bf16_t* kv_img;   // [B*S_img][3D] this layer
-    const bf16_t* kv_txt;   // [R][Tmax][3D] this layer (q at cols 0..D)
-    bf16_t* ctx;            // [R*T][D]
+// Attention sub-layer for text rows (txtblock.hip): query (r, t0+j) attends the image keys of clip r/beams and the text
+// keys 0..t0+j of row r -> this head's share of the output dense -> the last head of a row to arrive adds bias +
+// residual and applies LayerNorm.  One workgroup per (text row, head).
+struct TxtBlockArgs {
+    const bf16_t* kv_img;                       // [B*S_img][3D] this layer
+    const bf16_t* kv_txt;                       // [R][Tmax][3D] this layer (q | k | v of the text rows)
     int rows, beams, t0, T, Tmax, S_img, H, D;
+    const bf16_t* aow; const float *aob, *g1, *b1;   // output dense [D][D], bias, LayerNorm of the sub-layer
+    const float* xin;                           // [M][D] the sub-layer's input (residual)
+    float eps;
+    float* part;                                // [M][H][D] fp32 per-head partials of the output dense
+    unsigned* cnt;                              // [M] arrival tickets (zero between launches)
+    float* xs; bf16_t* xsb;                     // out: x1 [M][D] fp32 and bf16 (xs may alias xin)
+    int Mh;                                     // set by the launcher
 };
-hipError_t launch_attn_text(const TextAttnArgs& a, hipStream_t s);
+bool txt_block_ok(int D);
+hipError_t launch_txt_block(const TxtBlockArgs& a, hipStream_t s);
 
 // Small attention of the student decoder (student.hip): one wave per (query row, head), at most 64 keys,
 // any head_dim that is a multiple of 8 (<= 128).  Query m = (r, j), r = m / T: q at

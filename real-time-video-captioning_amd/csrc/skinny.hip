@@ -17,6 +17,7 @@
 //                  order, adds bias + residual and applies LayerNorm.  No atomics: results are
 //                  bitwise reproducible and independent of the batch size.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -166,8 +167,9 @@ hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s) {
 // K slabs: 16 for the K >= 2048 matrices, else the largest of 4, 3, 2 that leaves a supported per-slab depth
 // (768 -> 4 x 6, 3072 -> 16 x 6, 1024 -> 4 x 8; student decoder: 576 -> 3 x 6)
 int skinny_ksplit(int K) {
-    auto ok = [&](int ks) { const int k32 = K / (ks * 32); return K % (ks * 32) == 0 && (k32 == 1 || k32 == 2 || k32 == 6 || k32 == 8); };
-    if (K >= 2048) return ok(16) ? 16 : 0;
+    auto ok = [&](int ks) { const int k32 = K / (ks * 32); return K % (ks * 32) == 0 && (k32 == 1 || k32 == 2 || k32 == 6 || k32 == 8 || k32 == 12 || k32 == 24); };
+    static const int ks_big = getenv("GITCAP_FC2_KSPLIT") ? atoi(getenv("GITCAP_FC2_KSPLIT")) : 8;
+    if (K >= 2048) return ok(ks_big) ? ks_big : (ok(16) ? 16 : 0);
     for (int ks = 4; ks >= 1; --ks)
         if (ok(ks)) return ks;
     return 0;
@@ -182,6 +184,8 @@ hipError_t launch_skinny_splitk(const SkinnyArgs& a, hipStream_t s) {
         case 2: hipLaunchKernelGGL(skinny_splitk_kernel<2>, grid, dim3(64), 0, s, a); break;
         case 6: hipLaunchKernelGGL(skinny_splitk_kernel<6>, grid, dim3(64), 0, s, a); break;
         case 8: hipLaunchKernelGGL(skinny_splitk_kernel<8>, grid, dim3(64), 0, s, a); break;
+        case 12: hipLaunchKernelGGL(skinny_splitk_kernel<12>, grid, dim3(64), 0, s, a); break;
+        case 24: hipLaunchKernelGGL(skinny_splitk_kernel<24>, grid, dim3(64), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

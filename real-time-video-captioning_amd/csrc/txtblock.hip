@@ -1,0 +1,336 @@
+// Attention sub-layer of the GIT decoder for TEXT rows (one decode step, or T teacher-forced positions), fused from the
+// attention itself to the LayerNorm that closes the sub-layer.
+//
+// One 16-wave workgroup = one unit (text row m = (r, j), head):
+//   1. attention over the image keys of the row's clip + the text keys 0..t of the row.  q, k, v of the text rows were
+//      written to the text K/V cache by the q|k|v projection launch (skinny.hip).  K/V are streamed from HBM: the wave's
+//      first 32-key group by LDS-DMA (no registers while in flight), the others straight to VGPRs, 8 lanes per key,
+//      per-group online softmax; wave w takes the 32-key groups w, w+16, ... so the summation order depends on the key
+//      count only (batch invariant, bitwise)
+//   2. this head's share of the output dense: ctx_h[64] . Wo[:, 64h:64h+64]^T -> part[m][head][D] (fp32, write-through);
+//      the 6 KiB of weight fragments a wave needs arrive by LDS-DMA under the attention
+//   3. the LAST of the H units of a row to arrive (ticket counter; no unit ever waits for another) sums the H partials
+//      in head order, adds bias + residual and applies LayerNorm -> x1 (fp32) and bf16(x1) for the FC1 launch.
+// This replaces three launches of the first version (attention, split-K output dense, reduce + LayerNorm) by one.
+// Hand-off in 3 follows cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms": every payload store
+// is an agent-scope (sc1) store, every storing wave drains vmcnt before the workgroup barrier, ONE lane adds the ticket,
+// the reducer's loads are agent-scope (sc1) loads issued after the barrier its ticket lane joined.  No spin anywhere.
+//
+// Why the q|k|v projection is NOT in here (measured, tools/probe/txtblock_probe.hip): a CU pulls weight fragments at
+// ~30 GB/s whatever serves them (HBM, Infinity Cache or L2); 295 KB of q|k|v weights per (row, head) unit cost 10 us in
+// front of the attention, against 6 us for a launch of single-wave tiles that reads every weight byte once.
+#include "kernels.h"
+
+namespace {
+
+constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+struct Part { float m, l; float o[8]; };
+__device__ __forceinline__ void merge(Part& a, float m2, float l2, const float* o2) {
+    const float M = fmaxf(a.m, m2);
+    const float s1 = (a.m == -INFINITY) ? 0.f : ex2(a.m - M);
+    const float s2 = (m2 == -INFINITY) ? 0.f : ex2(m2 - M);
+    a.l = a.l * s1 + l2 * s2;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) a.o[d] = a.o[d] * s1 + o2[d] * s2;
+    a.m = M;
+}
+
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// phase stamps: only in the diagnostic build of tools/probe/txtblock_probe.hip (the product kernel has none)
+#ifdef TXT_STAMPS
+__device__ unsigned long long* g_txt_stamps;
+#define TXT_STAMP(i) do { if (threadIdx.x == 0 && g_txt_stamps) g_txt_stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TXT_STAMP(i) do {} while (0)
+#endif
+
+// sum over the 16 waves of the block (fixed order); `red` is a 16-float LDS array no one else is using
+__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w];
+    return s;
+}
+
+// y = LayerNorm over the D values held one per thread (tid < D); g, b = this thread's gamma / beta (loaded by the caller
+// together with its other loads, so that they are not a round trip of their own behind the two block sums)
+__device__ __forceinline__ float block_layernorm(float v, bool act, int D, float eps, float g, float b,
+                                                 float (*red)[16], int tid) {
+    TXT_STAMP(8);
+    const float mean = block_sum(act ? v : 0.f, red[0], tid) / (float)D;
+    TXT_STAMP(9);
+    const float d = act ? v - mean : 0.f;
+    const float rstd = rsqrtf(block_sum(d * d, red[1], tid) / (float)D + eps);
+    return act ? d * rstd * g + b : 0.f;
+}
+
+template <int K32>
+__global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
+    constexpr int D = K32 * 32;
+    __shared__ __attribute__((aligned(16))) bf16_t ctxs[64];
+    __shared__ float red[2][16];
+    __shared__ float wsm[16][8][10];
+    __shared__ int last_flag;
+    // per wave 8 KiB: the wave's first 32-key group (K 4 KiB | V 4 KiB) by LDS-DMA, then reused for the wave's
+    // output-dense weight fragments
+    __shared__ __attribute__((aligned(16))) char kvpre[16 * 8192];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = a.rows * a.T, H = a.H;
+    // unit -> (m, head).  H == 12: blocks that share an XCD (blockIdx % 8 equal) take whole heads (8 heads on 8 XCDs,
+    // heads 8..11 as half-heads of Mh | M - Mh rows), so a head's output-dense slice stays in ONE L2 and the beams of a
+    // clip (same image K/V) meet there too.  Placement only affects speed.
+    int m, head;
+    if (H == 12) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        if (slot < M) { m = slot; head = xcd; }
+        else {
+            const int s2 = slot - M;
+            head = 8 + (xcd >> 1);
+            m = (xcd & 1) ? a.Mh + s2 : s2;
+            if (m >= ((xcd & 1) ? M : a.Mh)) return;
+        }
+    } else {
+        m = blockIdx.x / H; head = blockIdx.x - m * H;
+        if (m >= M) return;
+    }
+    const int r = m / a.T, j = m - r * a.T;
+    const int clip = r / a.beams;
+    const int ld = 3 * D;
+    const int tq = a.t0 + j;
+    const int frow = lane & 15, fq = lane >> 4;
+    TXT_STAMP(0);
+
+    const int Lk = a.S_img + tq + 1;
+    const int sub = lane & 7, kk = lane >> 3;
+    const bf16_t* img = a.kv_img + (size_t)clip * a.S_img * ld + D + head * 64 + sub * 8;
+    const bf16_t* txt = a.kv_txt + (size_t)r * a.Tmax * ld + D + head * 64 + sub * 8;
+    char* mypre = kvpre + wid * 8192;
+    // group 0 of this wave (keys 32 wid .. +31) -> LDS, lane-linear (lane = kk*8 + sub, one 1-KiB piece per 8 keys)
+    auto dma_group0 = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int key = wid * 32 + u * 8 + kk;
+            key = key < Lk ? key : 0;
+            const bf16_t* kp = key < a.S_img ? img + (size_t)key * ld : txt + (size_t)(key - a.S_img) * ld;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(kp), LDS_PTR(mypre + u * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(kp + D), LDS_PTR(mypre + 4096 + u * 1024), 16, 0, 0);
+        }
+    };
+    if (wid * 32 < Lk) dma_group0();
+
+    TXT_STAMP(2);
+    // ---- 1: attention of (row, position tq, head) ------------------------------------------------------------------
+    float qv[8];
+    {
+        const bf16x8 q8 = *(const bf16x8*)(a.kv_txt + ((size_t)r * a.Tmax + tq) * ld + head * 64 + sub * 8);
+#pragma unroll
+        for (int d = 0; d < 8; ++d) qv[d] = bf2f((bf16_t)q8[d]) * kScaleLog2e;
+    }
+    Part st;
+    st.m = -INFINITY; st.l = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) st.o[d] = 0.f;
+
+    // Each wave owns only 2-3 groups of 32 keys (wid, wid+16, ...): group 0 is already in LDS, the loads of group
+    // i+1 are issued before group i is reduced (two register sets, static names).
+    auto load_group = [&](int g0, bf16x8* kf, bf16x8* vf, bool* valid) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int key = g0 + u * 8 + kk;
+            valid[u] = key < Lk;
+            key = valid[u] ? key : 0;
+            const bf16_t* kp = key < a.S_img ? img + (size_t)key * ld : txt + (size_t)(key - a.S_img) * ld;
+            kf[u] = *(const bf16x8*)kp;
+            vf[u] = *(const bf16x8*)(kp + D);
+        }
+    };
+    auto reduce_group = [&](const bf16x8* kf, const bf16x8* vf, const bool* valid) {
+        float sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) s += qv[d] * bf2f((bf16_t)kf[u][d]);
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            sc[u] = valid[u] ? s : -INFINITY;
+        }
+        const float mt = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        const float m_new = fmaxf(st.m, mt);
+        if (m_new != -INFINITY) {
+            const float alpha = (st.m == -INFINITY) ? 0.f : ex2(st.m - m_new);
+            st.l *= alpha;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) st.o[d] *= alpha;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float p = ex2(sc[u] - m_new);             // exp2(-inf) = 0 for masked keys
+                st.l += p;
+                const float pb = bf2f(f2bf(p));                 // P enters the PV product as bf16 (same rule as the MFMA path)
+#pragma unroll
+                for (int d = 0; d < 8; ++d) st.o[d] += pb * bf2f((bf16_t)vf[u][d]);
+            }
+            st.m = m_new;
+        }
+    };
+    constexpr int NT = (D / 16 + 15) / 16;                                 // out-projection: 16-column tiles per wave
+    auto dma_out_weights = [&]() {                                         // -> mypre, lane-linear: [tile][k-half][lane]
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int t = wid + 16 * i;
+            if (t < D / 16) {
+                const bf16_t* wp = a.aow + (size_t)(t * 16 + frow) * D + head * 64 + fq * 8;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(wp), LDS_PTR(mypre + (2 * i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(wp + 32), LDS_PTR(mypre + (2 * i + 1) * 1024), 16, 0, 0);
+            }
+        }
+    };
+    {
+        bf16x8 kA[4], vA[4], kB[4], vB[4];
+        bool okA[4], okB[4];
+        int g = wid * 32;
+        if (g < Lk) {
+            // Loads are issued unconditionally (a group past the last key reads key 0 and is masked): no branch
+            // ever merges a loaded register with an undefined one, so nothing waits for a load before its use.
+            load_group(g + 512, kB, vB, okB);
+            // vmcnt counts in issue order: all but the 8 youngest operations (group 1's loads) done = group 0 is in LDS
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                okA[u] = g + u * 8 + kk < Lk;
+                kA[u] = *(const bf16x8*)(mypre + u * 1024 + lane * 16);
+                vA[u] = *(const bf16x8*)(mypre + 4096 + u * 1024 + lane * 16);
+            }
+            reduce_group(kA, vA, okA);                                     // (waits for the LDS reads)
+            // the wave's 8 KiB are free again: its out-projection weight fragments arrive under the rest of the attention
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_out_weights();
+            g += 512;
+            while (g < Lk) {                                               // kB holds group g
+                load_group(g + 512, kA, vA, okA);
+                reduce_group(kB, vB, okB);
+                g += 512;
+                if (g >= Lk) break;
+                load_group(g + 512, kB, vB, okB);
+                reduce_group(kA, vA, okA);
+                g += 512;
+            }
+        } else {
+            dma_out_weights();
+        }
+    }
+    // merge the 8 key-groups of the wave (lanes with equal sub)
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+        const float m2 = __shfl_xor(st.m, off), l2 = __shfl_xor(st.l, off);
+        float o2[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) o2[d] = __shfl_xor(st.o[d], off);
+        merge(st, m2, l2, o2);
+    }
+    if (kk == 0) {
+        wsm[wid][sub][0] = st.m; wsm[wid][sub][1] = st.l;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) wsm[wid][sub][2 + d] = st.o[d];
+    }
+    __syncthreads();
+    if (tid < 8) {
+        Part t;
+        t.m = wsm[0][tid][0]; t.l = wsm[0][tid][1];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) t.o[d] = wsm[0][tid][2 + d];
+        for (int w = 1; w < 16; ++w) merge(t, wsm[w][tid][0], wsm[w][tid][1], &wsm[w][tid][2]);
+        const float inv = 1.0f / t.l;
+        uint4 v;
+        v.x = pack_bf2(t.o[0] * inv, t.o[1] * inv); v.y = pack_bf2(t.o[2] * inv, t.o[3] * inv);
+        v.z = pack_bf2(t.o[4] * inv, t.o[5] * inv); v.w = pack_bf2(t.o[6] * inv, t.o[7] * inv);
+        *(uint4*)(ctxs + tid * 8) = v;                                     // context enters the out-projection as bf16
+    }
+    __syncthreads();
+    TXT_STAMP(3);
+
+    // ---- 2: this head's share of the output dense ---------------------------------------------------------------
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the wave's own weight DMA (read by itself only)
+        const bf16x8 c0 = *(const bf16x8*)(ctxs + fq * 8), c1 = *(const bf16x8*)(ctxs + 32 + fq * 8);
+        float* pp = a.part + ((size_t)m * H + head) * D;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int t = wid + 16 * i;
+            if (t < D / 16) {
+                const bf16x8 w0 = *(const bf16x8*)(mypre + (2 * i) * 1024 + lane * 16);
+                const bf16x8 w1 = *(const bf16x8*)(mypre + (2 * i + 1) * 1024 + lane * 16);
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, c0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, c1, acc, 0, 0, 0);
+                if (frow == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) __hip_atomic_store(pp + t * 16 + fq * 4 + e, acc[e], RLX_AGENT);
+                }
+            }
+        }
+    }
+    // ---- 3: ticket; the last unit of the row reduces ---------------------------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // every storing wave, before the barrier
+    __syncthreads();
+    TXT_STAMP(4);
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.cnt + m, 1u, RLX_AGENT);
+        const int last = old == (unsigned)(H - 1);
+        if (last) __hip_atomic_store(a.cnt + m, 0u, RLX_AGENT);            // all H have arrived: ready for the next launch
+        last_flag = last;
+    }
+    __syncthreads();
+    TXT_STAMP(5);
+    if (!last_flag) return;
+    {
+        const bool act = tid < D;
+        float v = 0.f, g = 0.f, b = 0.f;
+        if (act) {
+            g = a.g1[tid]; b = a.b1[tid];
+            // all H partials are requested before the first add; summed in head order
+            float s = 0.f;
+            const float* pp = a.part + (size_t)m * H * D + tid;
+            for (int h0 = 0; h0 < H; h0 += 12) {
+                float p[12];
+#pragma unroll
+                for (int h = 0; h < 12; ++h) p[h] = (h0 + h < H) ? __hip_atomic_load(pp + (size_t)(h0 + h) * D, RLX_AGENT) : 0.f;
+#pragma unroll
+                for (int h = 0; h < 12; ++h) s += p[h];
+            }
+            v = s + (a.aob[tid] + a.xin[(size_t)m * D + tid]);
+        }
+        const float y = block_layernorm(v, act, D, a.eps, g, b, red, tid);
+        if (act) { a.xs[(size_t)m * D + tid] = y; a.xsb[(size_t)m * D + tid] = f2bf(y); }
+    }
+    TXT_STAMP(6);
+}
+
+}  // namespace
+
+bool txt_block_ok(int D) { return D == 128 || D == 768; }
+
+hipError_t launch_txt_block(const TxtBlockArgs& a_in, hipStream_t s) {
+    TxtBlockArgs a = a_in;
+    const int M = a.rows * a.T;
+    if (M <= 0 || a.H * 64 != a.D || a.beams <= 0 || !a.xin) return hipErrorInvalidValue;
+    // first "half" of the rows for heads 8..11 (H == 12 mapping): whole clips (all beams of a clip stay together)
+    const int unit = a.T == 1 ? a.beams : 1;
+    a.Mh = ((M / unit + 1) / 2) * unit;
+    const int grid = a.H == 12 ? 8 * (M + (a.Mh > M - a.Mh ? a.Mh : M - a.Mh)) : M * a.H;
+    switch (a.D) {
+        case 128: hipLaunchKernelGGL(txt_block_kernel<4>, dim3(grid), dim3(1024), 0, s, a); break;
+        case 768: hipLaunchKernelGGL(txt_block_kernel<24>, dim3(grid), dim3(1024), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
