@@ -75,6 +75,19 @@ int gitcap_load_tensor(gitcap_t* h, const char* name, const float* data,
                        const int64_t* shape, int rank);
 int gitcap_finalize_weights(gitcap_t* h);
 
+/* Storage of the GEMM weights in HBM (BASELINE.json configs[4]: "GIT-large fp8 weights"; the reference's teacher is
+ * data/teacher_configs/GIT_LARGE_MSRVTT/parameter.yaml:1-3).  Call before the first gitcap_load_tensor.
+ * GITCAP_W_FP8_E4M3: every GEMM weight is kept as OCP e4m3 bytes + one power-of-two fp32 scale per output row, half
+ * the bytes of bf16.  The values passed to gitcap_load_tensor must already be e4m3 x 2^k (weight-only quantisation is
+ * the caller's choice: gitcap.weights.quantize_weights_fp8); anything else is refused, nothing is rounded silently.
+ * The weight-streaming text kernels read the e4m3 bytes and expand them in registers; the big-tile GEMMs of the image
+ * pass read each panel through a bf16 staging buffer.  Arithmetic is unchanged (bf16 MFMA, fp32 accumulate): results
+ * are bitwise those of bf16 storage of the same values. */
+typedef enum { GITCAP_W_BF16 = 0, GITCAP_W_FP8_E4M3 = 1 } gitcap_weight_storage;
+int gitcap_set_weight_storage(gitcap_t* h, int storage);
+/* device bytes of all loaded tensors (weights, scales, tables, biases) */
+int gitcap_weight_bytes(const gitcap_t* h, int64_t* bytes);
+
 /* Replaces: self.image_encoder(torch.stack(batch['image'])) + temporal add + cat(dim=1)
  *                                                         src/models/model.py:378-382
  *           the 'linearLn' visual projection              src/models/model.py:699

@@ -17,13 +17,21 @@
 
 namespace {
 
+// a GEMM weight [Npad16][K]: bf16, or OCP e4m3 bytes + one power-of-two scale per row (scale != nullptr)
+struct WRef {
+    const void* p = nullptr; const float* scale = nullptr;
+    // rows n0.. of the matrix (K columns)
+    WRef rows_from(size_t n0, size_t K) const {
+        WRef r; r.p = (const char*)p + n0 * K * (scale ? 1 : 2); r.scale = scale ? scale + n0 : nullptr; return r;
+    }
+};
 struct EncLayer {
     const float *ln1w, *ln1b, *ln2w, *ln2b, *qkvb, *projb, *fc1b, *fc2b;
-    const bf16_t *qkvw, *projw, *fc1w, *fc2w;
+    WRef qkvw, projw, fc1w, fc2w;
 };
 struct DecLayer {
     const float *qkvb, *aob, *ln1w, *ln1b, *fc1b, *fc2b, *ln2w, *ln2b;
-    const bf16_t *qkvw, *aow, *fc1w, *fc2w;
+    WRef qkvw, aow, fc1w, fc2w;
 };
 
 }  // namespace
@@ -33,7 +41,10 @@ struct gitcap {
     int device = 0;
     mutable std::string err;
     std::map<std::string, DevTensor> w;
-    bool finalized = false;
+    std::map<std::string, float*> wscale;          // e4m3 storage: per-row scales of the GEMM weights
+    bool finalized = false, fp8 = false;
+    bf16_t* wstage = nullptr;                       // e4m3 storage: bf16 staging panel of the big-tile GEMMs
+    int64_t weight_bytes = 0;
 
     // derived sizes
     int N = 0, G = 0, Kp = 0, Dv = 0, D = 0, V = 0, Vp = 0;
@@ -56,7 +67,7 @@ struct gitcap {
     int* cand_idx = nullptr;
 
     // resolved weights
-    const bf16_t *patch_w = nullptr, *vproj_w = nullptr, *head_w = nullptr;
+    WRef patch_w, vproj_w, head_w;
     const float *cls = nullptr, *pos = nullptr, *ln_pre_w = nullptr, *ln_pre_b = nullptr, *ln_post_w = nullptr,
                 *ln_post_b = nullptr, *temporal = nullptr, *vproj_b = nullptr, *vproj_lnw = nullptr,
                 *vproj_lnb = nullptr, *word = nullptr, *tpos = nullptr, *txt_lnw = nullptr, *txt_lnb = nullptr,
@@ -72,7 +83,7 @@ struct gitcap {
     // batch's image pass (MFMA bound) runs on `s_enc`, the token loops of the batches submitted before
     // it (chains of tiny latency-bound kernels) interleave on the decode streams (slot i on stream i % n_txt)
     // (gitcap_greedy_submit / _wait).  The synchronous entry points always use slot 0 on the caller's
-    // stream; do not mix them with submissions that are still in flight.
+    // stream; they first make that stream wait for every submission still in flight (join_async).
     struct Slot {
         bf16_t* kv_img = nullptr; int32_t* sep_cnt = nullptr;
         // text-row workspace of the slot (token loops of different slots may run concurrently)
@@ -123,6 +134,27 @@ hipError_t launch_gemm_auto(const GemmArgs& a, int epi, hipStream_t s) {
     return g_persist ? launch_gemm256p(a, epi, s) : launch_gemm256(a, epi, s);
 }
 
+// OCP e4m3fn code of x, or -1 when x is not exactly representable (bias 7, 3 mantissa bits, max 448, no infinities)
+int host_e4m3_exact(float x) {
+    const int sign = std::signbit(x) ? 0x80 : 0;
+    const float a = std::fabs(x);
+    if (a == 0.f) return sign;
+    if (!(a <= 448.f)) return -1;
+    int e;
+    const float m = std::frexp(a, &e);          // a = m * 2^e, m in [0.5, 1)
+    const int E = e - 1 + 7;                    // a = (2m) * 2^(e-1)
+    if (E >= 1) {
+        const float f = (2.f * m - 1.f) * 8.f;  // mantissa field
+        const int M = (int)f;
+        if ((float)M != f) return -1;
+        return sign | (E << 3) | M;
+    }
+    const float f = std::ldexp(a, 9);           // subnormal: a = M * 2^-9
+    const int M = (int)f;
+    if ((float)M != f || M < 1 || M > 7) return -1;
+    return sign | M;
+}
+
 int fail(const gitcap* h, int code, const std::string& msg) {
     if (h) h->err = msg; else g_create_err = msg;
     return code;
@@ -137,6 +169,20 @@ void select_slot(gitcap* h, int i) {
     h->xs = n.xs; h->slabs = n.slabs; h->part = n.part; h->row_cnt = n.row_cnt; h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
     h->xsb = n.xsb; h->fs = n.fs; h->kv_txt = n.kv_txt; h->kv_txt2 = n.kv_txt2;
     h->cur_slot = i;
+}
+
+// Synchronous entry points (slot 0, caller's stream) share the image-row workspace with the submissions that
+// gitcap_greedy_submit put on the handle's own streams: before a synchronous call touches it, the caller's stream
+// waits for the token loop of every slot that has ever been submitted (each loop is ordered behind its image pass, so
+// this covers the encoder stream too).  A wait on an event that has already fired costs nothing on the device.
+hipError_t join_async(gitcap* h, hipStream_t stream) {
+    if (h->next_ticket == 0) return hipSuccess;
+    for (auto& sl : h->slots)
+        if (sl.used) {
+            hipError_t e = hipStreamWaitEvent(stream, sl.ev_dec, 0);
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
 }
 
 #define HIP_OK(h, expr)                                                                               \
@@ -224,28 +270,40 @@ int ln(gitcap* h, hipStream_t s, const float* x, int ldx, const float* g, const 
     return 0;
 }
 
-int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const bf16_t* W, const float* bias, int M, int N,
+// e4m3 storage: the big-tile GEMMs read a weight panel through the bf16 staging buffer (expanded right before the
+// launch, on the same stream: the panel is a few MB and stays in L2 / the Infinity Cache; HBM sees the e4m3 bytes)
+const bf16_t* stage_weight(gitcap* h, hipStream_t s, const WRef& W, int N, int K, hipError_t* e) {
+    *e = hipSuccess;
+    if (!W.scale) return (const bf16_t*)W.p;
+    *e = launch_dequant_fp8((const unsigned char*)W.p, W.scale, h->wstage, pad_to(N, 16), K, s);
+    return h->wstage;
+}
+
+int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef& W, const float* bias, int M, int N,
          int K, void* out, int ldo, const float* resid = nullptr, int ldr = 0) {
+    hipError_t e;
+    const bf16_t* Wb = stage_weight(h, s, W, N, K, &e);
+    HIP_OK(h, e);
     // algorithmic work: the VALID rows (h->prof_rows), not the 128-padded M that is launched
     ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * h->prof_rows * N * K, 0.0);
     GemmArgs a{};
-    a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
+    a.A = A; a.lda = lda; a.W = Wb; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
     a.resid = resid; a.ldr = ldr;
     HIP_OK(h, launch_gemm_auto(a, epi, s));
     return 0;
 }
 
-int skinny(gitcap* h, hipStream_t s, int epi, const bf16_t* X, int ldx, const bf16_t* W, const float* bias, int M,
+int skinny(gitcap* h, hipStream_t s, int epi, const bf16_t* X, int ldx, const WRef& W, const float* bias, int M,
            int N, int K, void* out, int ldo, int T = 1, int row_stride = 1, int row_off = 0) {
-    ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * M * N * K, 2.0 * N * K);
-    SkinnyArgs a{X, ldx, W, bias, M, N, K, out, ldo, T, row_stride, row_off, nullptr, nullptr};
+    ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * M * N * K, (W.scale ? 1.0 : 2.0) * N * K);
+    SkinnyArgs a{X, ldx, W.p, W.scale, bias, M, N, K, out, ldo, T, row_stride, row_off, nullptr, nullptr};
     HIP_OK(h, launch_skinny(a, epi, s));
     return 0;
 }
 
-int skinny_splitk(gitcap* h, hipStream_t s, const bf16_t* X, int ldx, const bf16_t* W, int M, int N, int K, float* slabs) {
-    ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * M * N * K, 2.0 * N * K);
-    SkinnyArgs a{X, ldx, W, nullptr, M, N, K, slabs, N, 1, 1, 0, nullptr, nullptr};
+int skinny_splitk(gitcap* h, hipStream_t s, const bf16_t* X, int ldx, const WRef& W, int M, int N, int K, float* slabs) {
+    ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * M * N * K, (W.scale ? 1.0 : 2.0) * N * K);
+    SkinnyArgs a{X, ldx, W.p, W.scale, nullptr, M, N, K, slabs, N, 1, 1, 0, nullptr, nullptr};
     HIP_OK(h, launch_skinny_splitk(a, s));
     return 0;
 }
@@ -283,7 +341,7 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
             if ((rc = ln(h, s, h->tmp, D, L.ln2w, L.ln2b, c.dec_ln_eps, rows, D, h->x, D, h->hb, D))) return rc;
         } else {
             // last layer: image rows are only ever read as keys/values -> K,V projections only
-            if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, D, L.qkvw + (size_t)D * D, L.qkvb + D, Mp, 2 * D, D, kv + D, 3 * D))) return rc;
+            if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, D, L.qkvw.rows_from(D, D), L.qkvb + D, Mp, 2 * D, D, kv + D, 3 * D))) return rc;
         }
     }
     h->cur_B = B; h->cur_S = S; h->have_image = true;
@@ -322,11 +380,11 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
             TxtBlockArgs ta{};
             ta.kv_img = h->kv_img + (size_t)l * kvi_layer; ta.kv_txt = kvt;
             ta.rows = rows; ta.beams = beams; ta.t0 = t0; ta.T = T; ta.Tmax = h->Tmax; ta.S_img = h->cur_S; ta.H = H; ta.D = D;
-            ta.aow = L.aow; ta.aob = L.aob; ta.g1 = L.ln1w; ta.b1 = L.ln1b; ta.xin = h->xs; ta.eps = c.dec_ln_eps;
+            ta.aow = L.aow.p; ta.aoscale = L.aow.scale; ta.aob = L.aob; ta.g1 = L.ln1w; ta.b1 = L.ln1b; ta.xin = h->xs; ta.eps = c.dec_ln_eps;
             ta.part = h->part; ta.cnt = h->row_cnt; ta.xs = h->xs; ta.xsb = h->xsb;
             double kvb = 0;
             for (int j = 0; j < T; ++j) kvb += (double)rows * (h->cur_S + t0 + j + 1) * 2 * D * 2;
-            ProfScope ps(h, GITCAP_PROF_ATTN_TEXT, s, 0.0, kvb + 2.0 * D * D);     // K/V read once + the output dense
+            ProfScope ps(h, GITCAP_PROF_ATTN_TEXT, s, 0.0, kvb + (L.aow.scale ? 1.0 : 2.0) * D * D);     // K/V read once + the output dense
             HIP_OK(h, launch_txt_block(ta, s));
         }
         if ((rc = skinny(h, s, SK_BIAS_GELU_BF16, h->xsb, D, L.fc1w, L.fc1b, M, c.dec_ffn, D, h->fs, c.dec_ffn))) return rc;
@@ -340,7 +398,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     // vocabulary head (+ arg-max partials per 16-column tile, reduced by argmax_final)
     const int V = c.vocab_size, ntiles = (V + 15) / 16;
     SkinnyArgs ha{};
-    ha.W = h->head_w; ha.bias = h->head_b; ha.N = V; ha.K = D; ha.ldo = V; ha.T = 1; ha.row_stride = 1; ha.row_off = 0;
+    ha.W = h->head_w.p; ha.wscale = h->head_w.scale; ha.bias = h->head_b; ha.N = V; ha.K = D; ha.ldo = V; ha.T = 1; ha.row_stride = 1; ha.row_off = 0;
     int am_stride = 1, am_off = 0;
     if (all_positions && logits_out) {
         ha.X = h->xsb; ha.ldx = D; ha.M = M; ha.out = logits_out;
@@ -350,7 +408,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     }
     if (argmax_out) { ha.amax_val = h->amax_val; ha.amax_idx = h->amax_idx; }
     {
-        ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * ha.M * V * D, 2.0 * V * D);
+        ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * ha.M * V * D, (ha.wscale ? 1.0 : 2.0) * V * D);
         HIP_OK(h, launch_skinny(ha, SK_BIAS_F32, s));
     }
     if (argmax_out)
@@ -503,6 +561,8 @@ void gitcap_destroy(gitcap_t* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     for (auto& kv : h->w)
         if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& kv : h->wscale)
+        if (kv.second) (void)hipFree(kv.second);
     delete h;
 }
 
@@ -516,8 +576,38 @@ int gitcap_load_tensor(gitcap_t* h, const char* name, const float* data, const i
     for (int i = 0; i < rank; ++i)
         if (t.shape[i] != shape[i]) return fail(h, GITCAP_ERR_ARG, std::string("load_tensor: shape mismatch for ") + name);
     const int64_t rows = rank == 2 ? shape[0] : 1, cols = rank == 2 ? shape[1] : shape[0];
-    if (t.p) { (void)hipFree(t.p); t.p = nullptr; }
-    if (t.bf16) {
+    if (t.p) { (void)hipFree(t.p); t.p = nullptr; h->weight_bytes -= t.bytes; t.bytes = 0; }
+    if (t.bf16 && h->fp8) {
+        // e4m3 storage: one power-of-two scale per row (the smallest that maps the row's amax into +-448), values
+        // must already BE e4m3 x 2^k (gitcap.weights.quantize_weights_fp8): this is a lossless re-encoding
+        const int64_t prow = pad_to((int)rows, 16), pcol = (strcmp(name, "enc.patch_w") == 0) ? h->Kp : cols;
+        std::vector<uint8_t> q((size_t)prow * pcol, 0);
+        std::vector<float> sc((size_t)prow, 1.0f);
+        for (int64_t r = 0; r < rows; ++r) {
+            float amax = 0.f;
+            for (int64_t k = 0; k < cols; ++k) amax = std::max(amax, std::fabs(data[(size_t)r * cols + k]));
+            int e = 0;
+            if (amax > 0.f) { (void)std::frexp(amax / 448.0f, &e); if (std::ldexp(1.0f, e - 1) * 448.0f >= amax) --e; }
+            const float scale = std::ldexp(1.0f, e);
+            sc[r] = scale;
+            for (int64_t k = 0; k < cols; ++k) {
+                int code = host_e4m3_exact(data[(size_t)r * cols + k] / scale);
+                if (code < 0)
+                    return fail(h, GITCAP_ERR_ARG, std::string("load_tensor: ") + name + " holds a value that is not e4m3 x 2^k "
+                                "(quantise first: gitcap.weights.quantize_weights_fp8)");
+                q[(size_t)r * pcol + k] = (uint8_t)code;
+            }
+        }
+        float* dsc = nullptr;
+        HIP_OK(h, hipMalloc(&t.p, q.size()));
+        HIP_OK(h, hipMemcpy(t.p, q.data(), q.size(), hipMemcpyHostToDevice));
+        HIP_OK(h, hipMalloc((void**)&dsc, sc.size() * 4));
+        HIP_OK(h, hipMemcpy(dsc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+        auto it2 = h->wscale.find(name);
+        if (it2 != h->wscale.end() && it2->second) (void)hipFree(it2->second);
+        h->wscale[name] = dsc;
+        t.bytes = (int64_t)(q.size() + sc.size() * 4);
+    } else if (t.bf16) {
         // GEMM weights: bf16, rows padded to 16 (zero rows), patch-embed K padded to a multiple of 64
         const int64_t prow = pad_to((int)rows, 16), pcol = (strcmp(name, "enc.patch_w") == 0) ? h->Kp : cols;
         std::vector<uint16_t> hb((size_t)prow * pcol, 0);
@@ -525,11 +615,14 @@ int gitcap_load_tensor(gitcap_t* h, const char* name, const float* data, const i
             for (int64_t k = 0; k < cols; ++k) hb[(size_t)r * pcol + k] = host_f2bf(data[(size_t)r * cols + k]);
         HIP_OK(h, hipMalloc(&t.p, hb.size() * 2));
         HIP_OK(h, hipMemcpy(t.p, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+        t.bytes = (int64_t)hb.size() * 2;
     } else {
         const size_t bytes = (size_t)rows * cols * 4;
         HIP_OK(h, hipMalloc(&t.p, bytes));
         HIP_OK(h, hipMemcpy(t.p, data, bytes, hipMemcpyHostToDevice));
+        t.bytes = (int64_t)bytes;
     }
+    h->weight_bytes += t.bytes;
     t.loaded = true;
     h->finalized = false;
     return 0;
@@ -541,7 +634,27 @@ int gitcap_finalize_weights(gitcap_t* h) {
     for (auto& kv : h->w)
         if (!kv.second.loaded) return fail(h, GITCAP_ERR_STATE, "finalize: tensor '" + kv.first + "' was never loaded");
     auto F = [&](const std::string& n) { return (const float*)h->w[n].p; };
-    auto Wt = [&](const std::string& n) { return (const bf16_t*)h->w[n].p; };
+    auto Wt = [&](const std::string& n) {
+        WRef r; r.p = h->w[n].p;
+        auto it = h->wscale.find(n);
+        r.scale = (h->fp8 && it != h->wscale.end()) ? it->second : nullptr;
+        return r;
+    };
+    if (h->fp8) {
+        for (auto& kv : h->w)
+            if (kv.second.bf16 && !h->wscale.count(kv.first))
+                return fail(h, GITCAP_ERR_STATE, "finalize: '" + kv.first + "' was loaded before gitcap_set_weight_storage(e4m3)");
+        if (!h->wstage) {          // bf16 staging panel of the big-tile GEMMs: the largest weight matrix
+            size_t mx = 0;
+            for (auto& kv : h->w)
+                if (kv.second.bf16 && kv.first != "head.w") {
+                    const size_t cols = kv.first == "enc.patch_w" ? (size_t)h->Kp : (size_t)kv.second.shape[1];
+                    mx = std::max(mx, (size_t)pad_to((int)kv.second.shape[0], 16) * cols);
+                }
+            int rc = ws_alloc(h, &h->wstage, mx);
+            if (rc) return rc;
+        }
+    }
     h->patch_w = Wt("enc.patch_w"); h->cls = F("enc.cls"); h->pos = F("enc.pos");
     h->ln_pre_w = F("enc.ln_pre.w"); h->ln_pre_b = F("enc.ln_pre.b");
     h->ln_post_w = F("enc.ln_post.w"); h->ln_post_b = F("enc.ln_post.b");
@@ -574,6 +687,7 @@ int gitcap_encode(gitcap_t* h, const float* frames, int B, int F, float* visual_
     if (!h) return fail(h, GITCAP_ERR_ARG, "encode: null handle");
     GUARD(h);
     select_slot(h, 0);
+    HIP_OK(h, join_async(h, (hipStream_t)stream));
     return encode_impl(h, frames, B, F, visual_out, (hipStream_t)stream);
 }
 
@@ -589,9 +703,12 @@ static int encode_impl(gitcap* h, const float* frames, int B, int F, float* visu
     // patchify (conv k = stride = p, no bias) + CLS + position embedding, then ln_pre
     HIP_OK(h, launch_im2col(frames, h->patches, nf, c.image_size, c.patch_size, h->Kp, s));
     {
+        hipError_t e;
+        const bf16_t* Wb = stage_weight(h, s, h->patch_w, Dv, h->Kp, &e);
+        HIP_OK(h, e);
         ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * P * Dv * (3.0 * c.patch_size * c.patch_size), 0.0);
         GemmArgs a{};
-        a.A = h->patches; a.lda = h->Kp; a.W = h->patch_w; a.bias = nullptr; a.M = Pp; a.N = Dv; a.K = h->Kp;
+        a.A = h->patches; a.lda = h->Kp; a.W = Wb; a.bias = nullptr; a.M = Pp; a.N = Dv; a.K = h->Kp;
         a.out = h->x; a.ldo = Dv; a.pos = h->pos; a.tokens_per_frame = N; a.patches_per_frame = h->G * h->G; a.valid_rows = P;
         HIP_OK(h, launch_gemm_auto(a, EPI_PATCH_F32, s));
     }
@@ -631,6 +748,7 @@ int gitcap_set_visual(gitcap_t* h, const float* visual, int B, int S_img, void* 
     if (((uintptr_t)visual & 15) != 0) return fail(h, GITCAP_ERR_ARG, "set_visual: visual must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     h->have_image = false;
+    HIP_OK(h, join_async(h, s));
     HIP_OK(h, launch_cast_bf16(visual, h->hb, (int64_t)B * S_img * h->Dv, s));
     return image_prefix(h, B, S_img, s);
 }
@@ -640,6 +758,7 @@ int gitcap_text_forward(gitcap_t* h, const int64_t* ids, int ld_ids, int rows, i
     if (!h) return fail(h, GITCAP_ERR_ARG, "text_forward: null handle");
     GUARD(h);
     select_slot(h, 0);
+    HIP_OK(h, join_async(h, (hipStream_t)stream));
     return text_forward(h, ids, ld_ids, rows, beams, t0, T, logits_out, all_positions, argmax_out, ld_argmax, nullptr, 0,
                         (hipStream_t)stream);
 }
@@ -673,6 +792,7 @@ int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, i
     int rc = greedy_check(h, max_len, stop, ids_out);
     if (rc) return rc;
     select_slot(h, 0);
+    HIP_OK(h, join_async(h, (hipStream_t)stream));
     if ((rc = encode_impl(h, frames, B, F, nullptr, (hipStream_t)stream))) return rc;
     return greedy_text_loop(h, B, max_len, stop, ids_out, steps_out, (hipStream_t)stream);
 }
@@ -719,8 +839,12 @@ int gitcap_beam_search(gitcap_t* h, const float* frames, int B, int F, int beams
     if (beams > h->c.max_beams || beams > 16 || beams * per_node_beam_size > 16)
         return fail(h, GITCAP_ERR_ARG, "beam_search: beams exceed max_beams / 16 candidates");
     if (max_steps < 2 || max_steps > h->Tmax) return fail(h, GITCAP_ERR_ARG, "beam_search: max_steps outside [2, max_text_len]");
+    // with fewer than 2 candidates per beam one EOS candidate leaves a sentence short of `beams` live beams, which the
+    // reference asserts against (model.py:606); the device bookkeeping has no way to report it, so refuse up front
+    if (per_node_beam_size < 2) return fail(h, GITCAP_ERR_ARG, "beam_search: per_node_beam_size must be >= 2 (model.py:606)");
     hipStream_t s = (hipStream_t)stream;
     select_slot(h, 0);
+    HIP_OK(h, join_async(h, s));
     int rc = encode_impl(h, frames, B, F, nullptr, s);
     if (rc) return rc;
     const int rows = B * beams, K = beams * per_node_beam_size, V = h->c.vocab_size, L = max_steps;
@@ -755,6 +879,7 @@ int gitcap_reorder_rows(gitcap_t* h, const int32_t* src_rows, int rows, int t_le
     if (!src_rows || rows <= 0 || rows > h->R || t_len < 0 || t_len > h->Tmax)
         return fail(h, GITCAP_ERR_ARG, "reorder_rows: bad arguments");
     hipStream_t s = (hipStream_t)stream;
+    HIP_OK(h, join_async(h, s));
     const size_t layer = (size_t)h->R * h->Tmax * 3 * h->D;
     for (int l = 0; l < h->c.dec_layers; ++l)
         HIP_OK(h, launch_gather_txt_rows(h->kv_txt + l * layer, h->kv_txt2 + l * layer, src_rows, rows, t_len, h->Tmax, 3 * h->D, s));
@@ -820,6 +945,21 @@ int gitcap_dbg_layernorm(const float* x, const float* gamma, const float* beta, 
                          float* out_f32, void* out_bf16, void* stream) {
     LnArgs a{x, D, gamma, beta, eps, rows, D, out_f32, D, (bf16_t*)out_bf16, D, nullptr, 1, 1};
     return launch_layernorm(a, (hipStream_t)stream) == hipSuccess ? 0 : GITCAP_ERR_HIP;
+}
+
+int gitcap_set_weight_storage(gitcap_t* h, int storage) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "set_weight_storage: null handle");
+    if (storage != GITCAP_W_BF16 && storage != GITCAP_W_FP8_E4M3) return fail(h, GITCAP_ERR_ARG, "set_weight_storage: unknown storage");
+    for (auto& kv : h->w)
+        if (kv.second.loaded && kv.second.bf16) return fail(h, GITCAP_ERR_STATE, "set_weight_storage: call it before the first gitcap_load_tensor");
+    h->fp8 = storage == GITCAP_W_FP8_E4M3;
+    return 0;
+}
+
+int gitcap_weight_bytes(const gitcap_t* h, int64_t* bytes) {
+    if (!h || !bytes) return GITCAP_ERR_ARG;
+    *bytes = h->weight_bytes;
+    return 0;
 }
 
 int gitcap_workspace_bytes(const gitcap_t* h, int64_t* bytes) {

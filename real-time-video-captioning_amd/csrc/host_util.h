@@ -9,8 +9,9 @@
 struct DevTensor {
     void* p = nullptr;
     std::vector<int64_t> shape;   // logical (unpadded) shape
-    bool bf16 = false;
+    bool bf16 = false;            // a GEMM weight (stored as bf16, or as e4m3 + row scales)
     bool loaded = false;
+    int64_t bytes = 0;            // device bytes held (incl. row scales)
 };
 
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }

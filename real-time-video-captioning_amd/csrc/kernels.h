@@ -32,7 +32,8 @@ hipError_t launch_gemm2b(const GemmArgs& a, int epi, hipStream_t s);    // 256(n
 enum SkinnyEpi { SK_BIAS_BF16 = 0, SK_BIAS_GELU_BF16 = 1, SK_BIAS_RELU_BF16 = 2, SK_BIAS_F32 = 3 };
 struct SkinnyArgs {
     const bf16_t* X; int ldx;     // bf16 activations, row m at X + m*ldx
-    const bf16_t* W;              // [Npad16][K]
+    const void* W;                // [Npad16][K] bf16, or e4m3 bytes when wscale != nullptr
+    const float* wscale;          // nullable: [Npad16] per-row power-of-two scale of e4m3 weights
     const float* bias;            // [N] (full kernel only)
     int M, N, K;                  // M valid rows, N valid cols (weight rows padded to 16)
     void* out;                    // full: row m -> out + orow(m)*ldo, orow(m) = (m / T)*row_stride + row_off + m % T
@@ -64,7 +65,9 @@ struct TxtBlockArgs {
     const bf16_t* kv_img;                       // [B*S_img][3D] this layer
     const bf16_t* kv_txt;                       // [R][Tmax][3D] this layer (q | k | v of the text rows)
     int rows, beams, t0, T, Tmax, S_img, H, D;
-    const bf16_t* aow; const float *aob, *g1, *b1;   // output dense [D][D], bias, LayerNorm of the sub-layer
+    const void* aow;                            // output dense [D][D]: bf16, or e4m3 bytes when aoscale != nullptr
+    const float* aoscale;                       // nullable: [D] per-row power-of-two scale of e4m3 weights
+    const float *aob, *g1, *b1;                 // its bias; LayerNorm of the sub-layer
     const float* xin;                           // [M][D] the sub-layer's input (residual)
     float eps;
     float* part;                                // [M][H][D] fp32 per-head partials of the output dense
@@ -110,6 +113,8 @@ hipError_t launch_im2col(const float* frames, bf16_t* patches, int nf, int img, 
 hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int nf, int N, int D, hipStream_t s);
 // f32 -> bf16 copy
 hipError_t launch_cast_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s);
+// e4m3 weight rows [rows][K] (+ per-row power-of-two scale) -> bf16 [rows][K] (exact); K % 16 == 0
+hipError_t launch_dequant_fp8(const unsigned char* w8, const float* scale, bf16_t* out, int rows, int K, hipStream_t s);
 // text embedding + LN: row m=(r, j) -> token ids[r*ld_ids + j], position t0 + j
 hipError_t launch_embed_text(const int64_t* ids, int ld_ids, int rows, int T, int t0,
                              const float* word, const float* pos, const float* gamma, const float* beta,

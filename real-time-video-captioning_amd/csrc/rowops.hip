@@ -108,6 +108,27 @@ __global__ void cast_bf16_kernel(const float* __restrict__ in, bf16_t* __restric
     *(uint2*)(out + i * 4) = w;
 }
 
+// e4m3 weight panel -> bf16 staging panel for the big-tile GEMMs (16 values per thread: 16-B read, 32-B write)
+__global__ __launch_bounds__(256) void dequant_fp8_kernel(const unsigned char* __restrict__ w8, const float* __restrict__ scale,
+                                                          bf16_t* __restrict__ out, int K, int64_t n16) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n16) return;
+    const int64_t e = i * 16;
+    const float sc = scale[e / K];
+    const uint4 q = *(const uint4*)(w8 + e);
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+    unsigned o[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[j], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[j], true);
+        o[2 * j] = pack_bf2(a[0] * sc, a[1] * sc);
+        o[2 * j + 1] = pack_bf2(b[0] * sc, b[1] * sc);
+    }
+    *(uint4*)(out + e) = make_uint4(o[0], o[1], o[2], o[3]);
+    *(uint4*)(out + e + 8) = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
 // ---- text embedding + LayerNorm: one wave per (row, position) ----------------------------------
 template <int NV>
 __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restrict__ ids, int ld_ids, int rows, int T,
@@ -560,6 +581,13 @@ hipError_t launch_cast_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t
     if (n % 4) return hipErrorInvalidValue;
     const int64_t n4 = n / 4;
     hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, in, out, n4);
+    return hipGetLastError();
+}
+
+hipError_t launch_dequant_fp8(const unsigned char* w8, const float* scale, bf16_t* out, int rows, int K, hipStream_t s) {
+    if (rows <= 0 || K <= 0 || K % 16) return hipErrorInvalidValue;
+    const int64_t n16 = (int64_t)rows * K / 16;
+    hipLaunchKernelGGL(dequant_fp8_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, w8, scale, out, K, n16);
     return hipGetLastError();
 }
 

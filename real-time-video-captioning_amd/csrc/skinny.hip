@@ -17,24 +17,42 @@
 //                  order, adds bias + residual and applies LayerNorm.  No atomics: results are
 //                  bitwise reproducible and independent of the batch size.
 #include "kernels.h"
-#include <cstdlib>
 
 namespace {
 
-template <int K32, int EPI>
+// weight fragments of one 16-row tile, K32 k-steps.  FP8: e4m3 bytes (8 per lane and k-step, half the stream),
+// expanded to bf16 in registers; the per-row power-of-two scale is applied to the accumulator (exact).
+template <int K32, bool FP8>
+__device__ __forceinline__ void load_wfrags(const void* W, size_t row, int K, int kofs, bf16x8 (&wf)[K32]) {
+    if (FP8) {
+        const unsigned char* wp = (const unsigned char*)W + row * K + kofs;
+        uint2 raw[K32];
+#pragma unroll
+        for (int k = 0; k < K32; ++k) raw[k] = *(const uint2*)(wp + k * 32);
+#pragma unroll
+        for (int k = 0; k < K32; ++k) wf[k] = fp8x8_to_bf16x8(raw[k]);
+    } else {
+        const bf16_t* wp = (const bf16_t*)W + row * K + kofs;
+#pragma unroll
+        for (int k = 0; k < K32; ++k) wf[k] = *(const bf16x8*)(wp + k * 32);
+    }
+}
+
+template <int K32, int EPI, bool FP8>
 __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
     const int lane = threadIdx.x;
     const int frow = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * 16;
-    const bf16_t* wp = a.W + (size_t)(n0 + frow) * a.K + fq * 8;
     bf16x8 wf[K32];
-#pragma unroll
-    for (int k = 0; k < K32; ++k) wf[k] = *(const bf16x8*)(wp + k * 32);
+    load_wfrags<K32, FP8>(a.W, (size_t)(n0 + frow), a.K, fq * 8, wf);
 
     const int n = n0 + fq * 4;
-    float bias[4];
+    float bias[4], wsc[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias[r] = (a.bias && n + r < a.N) ? a.bias[n + r] : 0.f;
+    for (int r = 0; r < 4; ++r) {
+        bias[r] = (a.bias && n + r < a.N) ? a.bias[n + r] : 0.f;
+        wsc[r] = FP8 ? a.wscale[n + r] : 1.f;                    // (weight rows are padded to 16: always in range)
+    }
 
     const int mtiles = (a.M + 15) >> 4;
     for (int mt = 0; mt < mtiles; ++mt) {
@@ -51,7 +69,7 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
         // lane holds out[m][n .. n+3]
         float y[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] = acc[r] + bias[r];
+        for (int r = 0; r < 4; ++r) y[r] = (FP8 ? acc[r] * wsc[r] : acc[r]) + bias[r];
         if (EPI == SK_BIAS_GELU_BF16) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = erf_gelu(y[r]);
@@ -103,17 +121,17 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
 }
 
 // grid = (n_tiles, ksplit); slab[ks][m][n] fp32 partial sums (no bias)
-template <int K32>
+template <int K32, bool FP8>
 __global__ __launch_bounds__(64) void skinny_splitk_kernel(SkinnyArgs a) {
     const int lane = threadIdx.x;
     const int frow = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * 16, ks = blockIdx.y;
     const int kbeg = ks * K32 * 32;
-    const bf16_t* wp = a.W + (size_t)(n0 + frow) * a.K + kbeg + fq * 8;
     bf16x8 wf[K32];
-#pragma unroll
-    for (int k = 0; k < K32; ++k) wf[k] = *(const bf16x8*)(wp + k * 32);
+    load_wfrags<K32, FP8>(a.W, (size_t)(n0 + frow), a.K, kbeg + fq * 8, wf);
     const int n = n0 + fq * 4;
+    f32x4 wsc = f32x4{1.f, 1.f, 1.f, 1.f};
+    if (FP8) wsc = *(const f32x4*)(a.wscale + n);
     float* slab = (float*)a.out + (size_t)ks * a.M * a.ldo;
     const int mtiles = (a.M + 15) >> 4;
     for (int mt = 0; mt < mtiles; ++mt) {
@@ -127,18 +145,18 @@ __global__ __launch_bounds__(64) void skinny_splitk_kernel(SkinnyArgs a) {
             const bf16x8 xf = *(const bf16x8*)(xp + k * 32);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k], xf, acc, 0, 0, 0);
         }
-        if (mvalid) *(f32x4*)(slab + (size_t)m * a.ldo + n) = acc;
+        if (mvalid) *(f32x4*)(slab + (size_t)m * a.ldo + n) = FP8 ? acc * wsc : acc;
     }
 }
 
-template <int K32>
+template <int K32, bool FP8>
 hipError_t launch_full(const SkinnyArgs& a, int epi, hipStream_t s) {
     const int grid = (a.N + 15) / 16;
     switch (epi) {
-        case SK_BIAS_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16>), dim3(grid), dim3(64), 0, s, a); break;
-        case SK_BIAS_GELU_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_GELU_BF16>), dim3(grid), dim3(64), 0, s, a); break;
-        case SK_BIAS_RELU_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_RELU_BF16>), dim3(grid), dim3(64), 0, s, a); break;
-        case SK_BIAS_F32: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_F32>), dim3(grid), dim3(64), 0, s, a); break;
+        case SK_BIAS_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16, FP8>), dim3(grid), dim3(64), 0, s, a); break;
+        case SK_BIAS_GELU_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_GELU_BF16, FP8>), dim3(grid), dim3(64), 0, s, a); break;
+        case SK_BIAS_RELU_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_RELU_BF16, FP8>), dim3(grid), dim3(64), 0, s, a); break;
+        case SK_BIAS_F32: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_F32, FP8>), dim3(grid), dim3(64), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -153,23 +171,29 @@ bool skinny_full_ok(int K) {
 
 hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s) {
     if (a.K % 32 || a.M <= 0 || a.T <= 0) return hipErrorInvalidValue;
+    if (a.wscale) {                                     // e4m3 weights (GIT decoder widths only)
+        switch (a.K / 32) {
+            case 4: return launch_full<4, true>(a, epi, s);
+            case 24: return launch_full<24, true>(a, epi, s);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (a.K / 32) {
-        case 2: return launch_full<2>(a, epi, s);      // K = 64  (tiny student test config)
-        case 4: return launch_full<4>(a, epi, s);      // K = 128 (tiny test config)
-        case 8: return launch_full<8>(a, epi, s);      // K = 256
-        case 18: return launch_full<18>(a, epi, s);    // K = 576 (student decoder)
-        case 24: return launch_full<24>(a, epi, s);    // K = 768
-        case 32: return launch_full<32>(a, epi, s);    // K = 1024
+        case 2: return launch_full<2, false>(a, epi, s);      // K = 64  (tiny student test config)
+        case 4: return launch_full<4, false>(a, epi, s);      // K = 128 (tiny test config)
+        case 8: return launch_full<8, false>(a, epi, s);      // K = 256
+        case 18: return launch_full<18, false>(a, epi, s);    // K = 576 (student decoder)
+        case 24: return launch_full<24, false>(a, epi, s);    // K = 768
+        case 32: return launch_full<32, false>(a, epi, s);    // K = 1024
     }
     return hipErrorInvalidValue;
 }
 
-// K slabs: 16 for the K >= 2048 matrices, else the largest of 4, 3, 2 that leaves a supported per-slab depth
-// (768 -> 4 x 6, 3072 -> 16 x 6, 1024 -> 4 x 8; student decoder: 576 -> 3 x 6)
+// K slabs: 8 (else 16) for the K >= 2048 matrices, else the largest of 4, 3, 2 that leaves a supported per-slab depth
+// (768 -> 4 x 6, 3072 -> 8 x 12, 4096 -> 16 x 8, 1024 -> 4 x 8; student decoder: 576 -> 3 x 6)
 int skinny_ksplit(int K) {
-    auto ok = [&](int ks) { const int k32 = K / (ks * 32); return K % (ks * 32) == 0 && (k32 == 1 || k32 == 2 || k32 == 6 || k32 == 8 || k32 == 12 || k32 == 24); };
-    static const int ks_big = getenv("GITCAP_FC2_KSPLIT") ? atoi(getenv("GITCAP_FC2_KSPLIT")) : 8;
-    if (K >= 2048) return ok(ks_big) ? ks_big : (ok(16) ? 16 : 0);
+    auto ok = [&](int ks) { const int k32 = K / (ks * 32); return K % (ks * 32) == 0 && (k32 == 1 || k32 == 2 || k32 == 6 || k32 == 8 || k32 == 12); };
+    if (K >= 2048) return ok(8) ? 8 : (ok(16) ? 16 : 0);
     for (int ks = 4; ks >= 1; --ks)
         if (ok(ks)) return ks;
     return 0;
@@ -179,13 +203,21 @@ hipError_t launch_skinny_splitk(const SkinnyArgs& a, hipStream_t s) {
     const int ks = skinny_ksplit(a.K);
     if (!ks || a.M <= 0 || a.N % 16) return hipErrorInvalidValue;
     dim3 grid(a.N / 16, ks);
+    if (a.wscale) {
+        switch (a.K / ks / 32) {
+            case 1: hipLaunchKernelGGL((skinny_splitk_kernel<1, true>), grid, dim3(64), 0, s, a); break;
+            case 2: hipLaunchKernelGGL((skinny_splitk_kernel<2, true>), grid, dim3(64), 0, s, a); break;
+            case 12: hipLaunchKernelGGL((skinny_splitk_kernel<12, true>), grid, dim3(64), 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (a.K / ks / 32) {
-        case 1: hipLaunchKernelGGL(skinny_splitk_kernel<1>, grid, dim3(64), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(skinny_splitk_kernel<2>, grid, dim3(64), 0, s, a); break;
-        case 6: hipLaunchKernelGGL(skinny_splitk_kernel<6>, grid, dim3(64), 0, s, a); break;
-        case 8: hipLaunchKernelGGL(skinny_splitk_kernel<8>, grid, dim3(64), 0, s, a); break;
-        case 12: hipLaunchKernelGGL(skinny_splitk_kernel<12>, grid, dim3(64), 0, s, a); break;
-        case 24: hipLaunchKernelGGL(skinny_splitk_kernel<24>, grid, dim3(64), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((skinny_splitk_kernel<1, false>), grid, dim3(64), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((skinny_splitk_kernel<2, false>), grid, dim3(64), 0, s, a); break;
+        case 6: hipLaunchKernelGGL((skinny_splitk_kernel<6, false>), grid, dim3(64), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((skinny_splitk_kernel<8, false>), grid, dim3(64), 0, s, a); break;
+        case 12: hipLaunchKernelGGL((skinny_splitk_kernel<12, false>), grid, dim3(64), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

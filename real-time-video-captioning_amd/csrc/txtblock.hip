@@ -70,7 +70,7 @@ __device__ __forceinline__ float block_layernorm(float v, bool act, int D, float
     return act ? d * rstd * g + b : 0.f;
 }
 
-template <int K32>
+template <int K32, bool FP8>
 __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
     constexpr int D = K32 * 32;
     __shared__ __attribute__((aligned(16))) bf16_t ctxs[64];
@@ -183,14 +183,21 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
         }
     };
     constexpr int NT = (D / 16 + 15) / 16;                                 // out-projection: 16-column tiles per wave
-    auto dma_out_weights = [&]() {                                         // -> mypre, lane-linear: [tile][k-half][lane]
+    auto dma_out_weights = [&]() {                                         // -> mypre, lane-linear
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const int t = wid + 16 * i;
             if (t < D / 16) {
-                const bf16_t* wp = a.aow + (size_t)(t * 16 + frow) * D + head * 64 + fq * 8;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(wp), LDS_PTR(mypre + (2 * i) * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(GLB_PTR(wp + 32), LDS_PTR(mypre + (2 * i + 1) * 1024), 16, 0, 0);
+                if (FP8) {      // e4m3: 8 bytes per lane and k-half, as two 4-byte pieces [tile][k-half][piece][lane]
+                    const unsigned char* wp = (const unsigned char*)a.aow + (size_t)(t * 16 + frow) * D + head * 64 + fq * 8;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        __builtin_amdgcn_global_load_lds(GLB_PTR(wp + (q >> 1) * 32 + (q & 1) * 4), LDS_PTR(mypre + (4 * i + q) * 256), 4, 0, 0);
+                } else {        // bf16: [tile][k-half][lane] 16 bytes
+                    const bf16_t* wp = (const bf16_t*)a.aow + (size_t)(t * 16 + frow) * D + head * 64 + fq * 8;
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(wp), LDS_PTR(mypre + (2 * i) * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(wp + 32), LDS_PTR(mypre + (2 * i + 1) * 1024), 16, 0, 0);
+                }
             }
         }
     };
@@ -267,14 +274,22 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
         for (int i = 0; i < NT; ++i) {
             const int t = wid + 16 * i;
             if (t < D / 16) {
-                const bf16x8 w0 = *(const bf16x8*)(mypre + (2 * i) * 1024 + lane * 16);
-                const bf16x8 w1 = *(const bf16x8*)(mypre + (2 * i + 1) * 1024 + lane * 16);
+                bf16x8 w0, w1;
+                if (FP8) {
+                    const unsigned* q = (const unsigned*)(mypre + (4 * i) * 256) + lane;
+                    w0 = fp8x8_to_bf16x8(make_uint2(q[0], q[64]));
+                    w1 = fp8x8_to_bf16x8(make_uint2(q[128], q[192]));
+                } else {
+                    w0 = *(const bf16x8*)(mypre + (2 * i) * 1024 + lane * 16);
+                    w1 = *(const bf16x8*)(mypre + (2 * i + 1) * 1024 + lane * 16);
+                }
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, c0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, c1, acc, 0, 0, 0);
                 if (frow == 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) __hip_atomic_store(pp + t * 16 + fq * 4 + e, acc[e], RLX_AGENT);
+                    for (int e = 0; e < 4; ++e)      // e4m3 weights: the row's power-of-two scale goes on the accumulator (exact)
+                        __hip_atomic_store(pp + t * 16 + fq * 4 + e, FP8 ? acc[e] * a.aoscale[t * 16 + fq * 4 + e] : acc[e], RLX_AGENT);
                 }
             }
         }
@@ -327,9 +342,12 @@ hipError_t launch_txt_block(const TxtBlockArgs& a_in, hipStream_t s) {
     const int unit = a.T == 1 ? a.beams : 1;
     a.Mh = ((M / unit + 1) / 2) * unit;
     const int grid = a.H == 12 ? 8 * (M + (a.Mh > M - a.Mh ? a.Mh : M - a.Mh)) : M * a.H;
-    switch (a.D) {
-        case 128: hipLaunchKernelGGL(txt_block_kernel<4>, dim3(grid), dim3(1024), 0, s, a); break;
-        case 768: hipLaunchKernelGGL(txt_block_kernel<24>, dim3(grid), dim3(1024), 0, s, a); break;
+    const int key = a.D * 2 + (a.aoscale ? 1 : 0);
+    switch (key) {
+        case 256: hipLaunchKernelGGL((txt_block_kernel<4, false>), dim3(grid), dim3(1024), 0, s, a); break;
+        case 257: hipLaunchKernelGGL((txt_block_kernel<4, true>), dim3(grid), dim3(1024), 0, s, a); break;
+        case 1536: hipLaunchKernelGGL((txt_block_kernel<24, false>), dim3(grid), dim3(1024), 0, s, a); break;
+        case 1537: hipLaunchKernelGGL((txt_block_kernel<24, true>), dim3(grid), dim3(1024), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

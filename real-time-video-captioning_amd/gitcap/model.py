@@ -18,6 +18,7 @@ in the hand-written gfx950 kernels behind the C ABI (include/gitcap.h).
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import Dict, Mapping, Optional
 
 import numpy as np
@@ -55,11 +56,7 @@ class CaptionFuture:
         if self._sub is None:                    # still waiting for partners to coalesce with: run now
             m._flush_pending()
         sub = self._sub
-        if not sub.waited:
-            with torch.cuda.device(m._dev):
-                m._call("gitcap_greedy_wait", sub.ticket, m._stream())
-            sub.waited = True
-            sub.frames = None
+        m._wait_submission(sub)
         ids = sub.ids[self._r0:self._r1]
         if self._mode == STOP_ALL_SEP:
             if sub.coalesced:                    # reference rule over THIS caller batch (model.py:184)
@@ -110,6 +107,7 @@ class GitCaptioner(nn.Module):
         self._weights: Optional[Dict[str, np.ndarray]] = None
         self._last_memory = None
         self._pending, self._pending_key = [], None
+        self._inflight = []                             # submissions whose wait has not been enqueued yet (<= 4)
         self._lib = _lib.load()                         # raises if libgitcap.so is missing
         self._create()
         if weights is not None:
@@ -133,6 +131,8 @@ class GitCaptioner(nn.Module):
         rc = self._lib.gitcap_create(ctypes.byref(cc), idx, ctypes.byref(h))
         _lib.check(self._lib, None, rc, "gitcap_create")
         self._handle = h
+        if self.weight_dtype == "fp8_e4m3":     # GEMM weights live in HBM as e4m3 + per-row 2^k scale (half the bytes)
+            self._call("gitcap_set_weight_storage", 1)
 
     def __del__(self):
         try:
@@ -148,6 +148,27 @@ class GitCaptioner(nn.Module):
     def _call(self, name, *args):
         rc = getattr(self._lib, name)(self._handle, *args)
         _lib.check(self._lib, self._handle, rc, name)
+
+    # ------------------------------------------------------------------ submissions in flight
+    def _wait_submission(self, sub):
+        """Make the current stream wait for a submission (once).  Its frames/ids/steps buffers are owned by the
+        model-side table until then: dropping a future early cannot hand them back to the allocator while the
+        library's streams still read frames / write ids."""
+        if not sub.waited:
+            with torch.cuda.device(self._dev):
+                self._call("gitcap_greedy_wait", sub.ticket, self._stream())
+            sub.waited = True
+            sub.frames = None
+        if sub in self._inflight:
+            self._inflight.remove(sub)
+
+    def _drain(self):
+        """Before a synchronous call: submit what is still waiting to coalesce and order the current stream behind
+        every submission in flight (the C ABI orders the device work as well; this releases the buffers)."""
+        if self._pending:
+            self._flush_pending()
+        for sub in list(self._inflight):
+            self._wait_submission(sub)
 
     # ------------------------------------------------------------------ nn.Module surface
     def to(self, *args, **kwargs):
@@ -228,6 +249,7 @@ class GitCaptioner(nn.Module):
         """-> ([], memory) with memory = visual features [B, F*N, Dv] (ln_post + temporal embedding,
         frames concatenated along tokens, model.py:378-382).  Also leaves the decoder's image K/V
         in the handle."""
+        self._drain()
         fr = self._frames(x)
         B, F = fr.shape[:2]
         if B > self.max_batch:
@@ -235,20 +257,29 @@ class GitCaptioner(nn.Module):
         vis = torch.empty((B, F * self.cfg.tokens_per_frame, self.cfg.enc_width), dtype=torch.float32, device=self._dev)
         with torch.cuda.device(self._dev):
             self._call("gitcap_encode", ctypes.c_void_p(fr.data_ptr()), B, F, ctypes.c_void_p(vis.data_ptr()), self._stream())
-        self._last_memory = (vis.data_ptr(), vis._version, tuple(vis.shape))
+        self._remember_memory(vis)
         return [], vis
+
+    def _remember_memory(self, t: torch.Tensor):
+        # identity (a weak reference that dies with the tensor) + version: a recycled address cannot alias it
+        self._last_memory = (weakref.ref(t), t._version)
+
+    def _is_last_memory(self, t: torch.Tensor) -> bool:
+        lm = self._last_memory
+        return lm is not None and lm[0]() is t and lm[1] == t._version
 
     @torch.no_grad()
     def forward_decoder(self, y: torch.Tensor, memory: torch.Tensor) -> torch.Tensor:
         """Teacher-forced logits [B,T,V] for token prefixes y [B,T] given `memory` from
         forward_image_enc (block mask: text->image full, text->text causal)."""
+        self._drain()
         ids = self._ids(y)
         B, T = ids.shape
         with torch.cuda.device(self._dev):
-            if self._last_memory != (memory.data_ptr(), memory._version, tuple(memory.shape)):
+            if not self._is_last_memory(memory):
                 mem = memory.to(device=self._dev, dtype=torch.float32).contiguous()
                 self._call("gitcap_set_visual", ctypes.c_void_p(mem.data_ptr()), mem.shape[0], mem.shape[1], self._stream())
-                self._last_memory = (memory.data_ptr(), memory._version, tuple(memory.shape))
+                self._remember_memory(memory)
             logits = torch.empty((B, T, self.cfg.vocab_size), dtype=torch.float32, device=self._dev)
             self._call("gitcap_text_forward", ctypes.c_void_p(ids.data_ptr()), T, B, 1, 0, T,
                        ctypes.c_void_p(logits.data_ptr()), 1, None, 0, self._stream())
@@ -311,6 +342,7 @@ class GitCaptioner(nn.Module):
         mode = {"all_sep": STOP_ALL_SEP, "never": STOP_NEVER}[stop]
         if max_len > self.max_text_len:
             raise ValueError(f"max_len {max_len} > max_text_len={self.max_text_len} the handle was created for")
+        self._drain()
         fr = self._frames(src)
         B, F = fr.shape[:2]
         outs, steps_all = [], []
@@ -375,6 +407,8 @@ class GitCaptioner(nn.Module):
         frames = group[0]._frames if len(group) == 1 else torch.cat([f._frames for f in group], 0)
         B, F = frames.shape[:2]
         max_len, mode = group[0]._max_len, group[0]._mode
+        while len(self._inflight) >= 4:        # four slots: the oldest submission's slot is about to be reused
+            self._wait_submission(self._inflight[0])
         with torch.cuda.device(self._dev):
             ids = torch.empty((B, max_len + 1), dtype=torch.int64, device=self._dev)
             steps = torch.zeros((1,), dtype=torch.int32, device=self._dev)
@@ -385,6 +419,7 @@ class GitCaptioner(nn.Module):
                        ctypes.byref(ticket))
         self._last_memory = None
         shared = _Submission(ticket.value, ids, steps, frames, len(group) > 1)
+        self._inflight.append(shared)
         r0 = 0
         for f in group:
             n = f._frames.shape[0]
@@ -395,6 +430,7 @@ class GitCaptioner(nn.Module):
     def step_logits(self, ids_last: torch.Tensor, t: int, beams: int = 1) -> torch.Tensor:
         """One KV-cached decoding step = `scores = step(input_ids)` of model.py:519: ids_last [rows]
         is the token at text position t of every row; returns fp32 logits [rows, V]."""
+        self._drain()
         ids = self._ids(ids_last).view(-1, 1)
         rows = ids.shape[0]
         logits = torch.empty((rows, self.cfg.vocab_size), dtype=torch.float32, device=self._dev)
@@ -418,13 +454,19 @@ class GitCaptioner(nn.Module):
             raise ValueError(f"beam_size {beam_size} > max_beams={self.max_beams} the handle was created for")
         if max_steps > self.max_text_len:
             raise ValueError(f"max_steps {max_steps} > max_text_len={self.max_text_len}")
+        self._drain()
         fr = self._frames(src)
         B, F = fr.shape[:2]
         if B > self.max_batch:
             raise ValueError(f"batch {B} > max_batch={self.max_batch}")
         if on_device is None:
-            on_device = num_keep_best == 1 and not save_logits and beam_size * per_node_beam_size <= 16
+            on_device = (num_keep_best == 1 and not save_logits and beam_size * per_node_beam_size <= 16
+                         and per_node_beam_size >= 2)
         if on_device:
+            if per_node_beam_size < 2:
+                raise ValueError("the device-resident search needs per_node_beam_size >= 2: with one candidate per beam "
+                                 "a single EOS leaves fewer than beam_size live beams (model.py:606 asserts against it); "
+                                 "the host operator (on_device=False) raises when that happens")
             # the whole search on the GPU, no per-step host sync (gitcap_beam_search)
             if num_keep_best != 1 or save_logits:
                 raise ValueError("the device-resident search keeps one hypothesis and does not export per-step logits")
@@ -476,6 +518,12 @@ class GitCaptioner(nn.Module):
             self._call("gitcap_profile_read", i, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
             out[name] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
         return out
+
+    def weight_bytes(self) -> int:
+        """Device bytes of the loaded tensors (GEMM weights + scales, tables, biases)."""
+        n = ctypes.c_int64()
+        self._lib.gitcap_weight_bytes(self._handle, ctypes.byref(n))
+        return n.value
 
     def workspace_bytes(self) -> int:
         n = ctypes.c_int64()

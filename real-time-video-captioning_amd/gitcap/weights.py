@@ -111,6 +111,21 @@ def _np(t) -> np.ndarray:
     return np.ascontiguousarray(t, dtype=np.float32)
 
 
+def _temporal_rows(cfg: GitCapConfig, sd, patterns, g) -> np.ndarray:
+    """Per-frame temporal embeddings [F, Dv] (model.py:380).  cfg.num_frames > 0 means the model adds one per frame: a
+    frame whose key is missing under every known spelling is an error, never a silent row of zeros."""
+    F = max(1, cfg.num_frames)
+    temporal = np.zeros((F, cfg.enc_width), np.float32)
+    for f in range(F):
+        keys = [p.format(f) for p in patterns]
+        hit = next((k for k in keys if k in sd), None)
+        if hit is not None:
+            temporal[f] = g(hit).reshape(-1)
+        elif cfg.num_frames > 0:
+            raise KeyError(f"temporal embedding of frame {f} not in the checkpoint (looked for {keys})")
+    return temporal
+
+
 def from_hf_state_dict(cfg: GitCapConfig, sd: Mapping[str, object]) -> Dict[str, np.ndarray]:
     """transformers.GitForCausalLM state-dict -> canonical (q/k/v fused into one matrix)."""
     g = lambda k: _np(sd[k])
@@ -130,13 +145,8 @@ def from_hf_state_dict(cfg: GitCapConfig, sd: Mapping[str, object]) -> Dict[str,
         w[p + "ln2.w"] = g(s + "layer_norm2.weight"); w[p + "ln2.b"] = g(s + "layer_norm2.bias")
         w[p + "fc1.w"] = g(s + "mlp.fc1.weight"); w[p + "fc1.b"] = g(s + "mlp.fc1.bias")
         w[p + "fc2.w"] = g(s + "mlp.fc2.weight"); w[p + "fc2.b"] = g(s + "mlp.fc2.bias")
-    F = max(1, cfg.num_frames)
-    temporal = np.zeros((F, cfg.enc_width), np.float32)
-    for f in range(F):
-        k = f"git.img_temporal_embedding.{f}"
-        if k in sd:
-            temporal[f] = g(k).reshape(-1)
-    w["temporal"] = temporal
+    # transformers 5.x spells the list "img_temporal_embedding", 4.x (and the checkpoints it wrote) "img_temperal_embedding"
+    w["temporal"] = _temporal_rows(cfg, sd, ("git.img_temporal_embedding.{}", "git.img_temperal_embedding.{}"), g)
     w["vproj.w"] = g("git.visual_projection.visual_projection.0.weight")
     w["vproj.b"] = g("git.visual_projection.visual_projection.0.bias")
     w["vproj.ln.w"] = g("git.visual_projection.visual_projection.1.weight")
@@ -231,13 +241,7 @@ def from_ms_state_dict(cfg: GitCapConfig, sd: Mapping[str, object]) -> Dict[str,
         w[p + "ln2.w"] = g(s + "ln_2.weight"); w[p + "ln2.b"] = g(s + "ln_2.bias")
         w[p + "fc1.w"] = g(s + "mlp.c_fc.weight"); w[p + "fc1.b"] = g(s + "mlp.c_fc.bias")
         w[p + "fc2.w"] = g(s + "mlp.c_proj.weight"); w[p + "fc2.b"] = g(s + "mlp.c_proj.bias")
-    F = max(1, cfg.num_frames)
-    temporal = np.zeros((F, cfg.enc_width), np.float32)
-    for f in range(F):
-        k = f"img_temperal_embedding.{f}"
-        if k in sd:
-            temporal[f] = g(k).reshape(-1)
-    w["temporal"] = temporal
+    w["temporal"] = _temporal_rows(cfg, sd, ("img_temperal_embedding.{}", "img_temporal_embedding.{}"), g)
     t = "textual."
     w["vproj.w"] = g(t + "visual_projection.0.weight"); w["vproj.b"] = g(t + "visual_projection.0.bias")
     w["vproj.ln.w"] = g(t + "visual_projection.1.weight"); w["vproj.ln.b"] = g(t + "visual_projection.1.bias")
@@ -270,8 +274,8 @@ def quantize_weights_fp8(w: Mapping[str, np.ndarray]) -> Dict[str, np.ndarray]:
     e4m3's +-448 range), returned DEQUANTISED as fp32.  Because the scale is a power of two and e4m3
     has a 4-bit significand, every returned value is exactly representable in bf16, so the big-tile
     GEMMs and the weight-streaming text kernels see bit-identical weights.  Tables, biases and
-    LayerNorm parameters stay fp32.  (Storage: this round the device keeps the dequantised bf16
-    copy; fp8 storage for the weight-streaming kernels is listed as next in DESIGN.md.)"""
+    LayerNorm parameters stay fp32.  With ``weight_dtype="fp8_e4m3"`` the library re-encodes these values
+    losslessly as e4m3 bytes + one fp32 scale per row (gitcap_set_weight_storage)."""
     import torch
     out: Dict[str, np.ndarray] = {}
     for k, v in w.items():

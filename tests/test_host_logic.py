@@ -80,6 +80,21 @@ def test_ms_checkpoint_layout_import():
         assert np.array_equal(w[k], back[k]), k
 
 
+def test_hf_import_accepts_legacy_temporal_key_and_refuses_a_missing_one():
+    """transformers 4.x (and the video checkpoints it wrote) spell the list `img_temperal_embedding`; 5.x
+    `img_temporal_embedding`.  Both must import; a frame with neither is an error, not a row of zeros."""
+    cfg = git_tiny(2)
+    w = W.synthetic_weights(cfg, 5)
+    sd = W.to_hf_state_dict(cfg, w)
+    legacy = {k.replace("img_temporal_embedding", "img_temperal_embedding"): v for k, v in sd.items()}
+    assert any("img_temperal_embedding" in k for k in legacy) and not any("img_temporal_embedding" in k for k in legacy)
+    back = W.from_hf_state_dict(cfg, legacy)
+    assert np.array_equal(back["temporal"], w["temporal"]) and np.abs(w["temporal"]).max() > 0
+    broken = {k: v for k, v in sd.items() if not k.endswith("img_temporal_embedding.1")}
+    with pytest.raises(KeyError):
+        W.from_hf_state_dict(cfg, broken)
+
+
 def test_check_shapes_rejects_wrong_and_missing():
     cfg = git_tiny(2)
     w = W.synthetic_weights(cfg, 0)

@@ -57,7 +57,12 @@ def test_raw_frames_to_caption():
     a = m.greedy_decode(dev_in, max_len=10, stop="never").cpu()
     b = m.greedy_decode(host_in, max_len=10, stop="never")
     assert a.shape == (1, 11)
-    agree = float((a == b).float().mean())
-    assert agree > 0.6, agree          # identical up to near-ties (inputs differ by <= 2e-4)
+    # the two inputs differ by <= 2e-4 per pixel: the captions agree up to the first near-tie, and every token the
+    # device-preprocessed path chose is (within 0.05 of) the arg-max under the host-preprocessed frames
+    lg = m(host_in, a[:, :-1])
+    gap = lg.max(-1).values - lg.gather(2, a[:, 1:, None].to(lg.device)).squeeze(-1)
+    assert float(gap.max()) < 0.05, gap
+    first = int((a != b).any(0).float().argmax()) if bool((a != b).any()) else a.shape[1]
+    assert first == a.shape[1] or float(gap[0, first - 1]) > 0, (a, b)
     with pytest.raises(ValueError):
         preprocess_frames(torch.zeros(4, 4, 3))

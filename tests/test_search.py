@@ -1,6 +1,7 @@
 """Search operator: the oracle restatement of model.py:479-678 against exhaustive enumeration, and (GPU)
 the product's GeneratorWithBeamSearch + beam_topk kernel against that oracle."""
 import itertools
+import numpy as np
 import math
 
 import pytest
@@ -203,3 +204,53 @@ def test_device_beam_search_vs_oracle_tiny_model():
     assert torch.equal(m.beam_search(fr, max_len=8, k=4).cpu(), out["predictions"].cpu())
     # greedy still works on the same handle afterwards (slot state intact)
     assert m.greedy_decode(fr, max_len=6, stop="never").shape == (2, 7)
+
+
+def _beam_golden():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "beam_tiny.npz"))
+    cases = sorted(k[:-4] for k in g.files if k.endswith("_ids"))
+    return g, cases
+
+
+def test_oracle_reproduces_beam_golden():
+    """SURVEY.md par. 8c fixture (3): the committed beam ids / log-probabilities of the GIT tiny config come from
+    oracle/gen_golden_beam.py (restated search loop of model.py:479-678 over the fp32 oracle's step); the oracle
+    must still reproduce them."""
+    from oracle import gen_golden_beam as G
+    g, cases = _beam_golden()
+    assert len(cases) == 3
+    with torch.no_grad():
+        for c in G.CASES:
+            dec, lp = G.run(c)
+            assert np.array_equal(dec.numpy(), g[c["name"] + "_ids"]), c["name"]
+            assert np.allclose(lp.numpy(), g[c["name"] + "_logprobs"], atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_device_beam_search_vs_committed_golden():
+    """gitcap_beam_search (device resident) and the host operator against the committed fp32 goldens: same
+    hypothesis, or -- where bf16 operand noise flips a near-tie between hypotheses -- one that scores within noise."""
+    from gitcap.config import git_tiny
+    from gitcap.model import GitCaptioner
+    from gitcap.weights import synthetic_weights
+    from oracle.git_oracle import make_frames
+    g, cases = _beam_golden()
+    cfg = git_tiny(int(g["F"]))
+    m = GitCaptioner(cfg, synthetic_weights(cfg, int(g["weight_seed"])), max_batch=2, max_text_len=16, max_beams=4)
+    fr = make_frames(int(g["B"]), int(g["F"]), cfg.image_size, int(g["frame_seed"]))
+    exact = 0
+    for name in cases:
+        beams, steps, lp = g[name + "_cfg"]
+        for on_device in (True, False):
+            out = m.infer(fr, beam_size=int(beams), max_steps=int(steps), length_penalty=float(lp), on_device=on_device)
+            got, glp = out["predictions"].cpu().numpy(), out["logprobs"].cpu().numpy().reshape(-1)
+            want, wlp = g[name + "_ids"], g[name + "_logprobs"].reshape(-1)
+            assert got.shape == want.shape
+            assert np.abs(glp - wlp).max() < 0.05, (name, glp, wlp)          # bf16 operand noise on a sum of log-probs
+            for b in range(got.shape[0]):
+                if np.array_equal(got[b], want[b]):
+                    exact += 1
+                else:
+                    assert abs(glp[b] - wlp[b]) < 0.02, (name, b, got[b], want[b])
+    assert exact >= 8, exact        # of 12 (3 cases x 2 clips x 2 drivers)
