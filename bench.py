@@ -34,6 +34,30 @@ MFMA_PEAK_TFLOPS = 2500.0          # dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
 
+def library_source_sha() -> str:
+    """Fingerprint of the kernel sources the library was built from (csrc/*.hip, *.h): profiles/ records the same
+    fingerprint next to the PMC-derived traffic, so a `roofline.traffic` measured on older kernels is visible."""
+    import hashlib
+    d = os.path.join(ROOT, "real-time-video-captioning_amd", "csrc")
+    hsh = hashlib.sha1()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            hsh.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                hsh.update(f.read())
+    return hsh.hexdigest()[:12]
+
+
+def decode_phase_bytes(cfg, clips: int, frames: int, tokens: int) -> float:
+    """SURVEY.md par. 8(d): algorithmic HBM bytes of the token loop (bf16): every step reads the decoder + head weights
+    once and, per clip, the image + text K/V of all layers."""
+    D, V, Ld = cfg.dec_width, cfg.vocab_size, cfg.dec_layers
+    weights = (Ld * (4 * D * D + 2 * D * cfg.dec_ffn) + D * V) * 2.0
+    s_img = frames * cfg.tokens_per_frame
+    kv = sum(clips * Ld * 2 * (s_img + t + 1) * D * 2.0 for t in range(tokens))
+    return tokens * weights + kv
+
+
 def cpu_baseline(cfg, weights, budget_s: float = 25.0):
     """oracle/git_oracle.py (fp32, encoder once + exact KV cache, batch 1) timed on the host cores:
     the CPU restatement of the same path, a bounded sample of the same workload."""
@@ -71,6 +95,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is repeated; the median repeat is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--serial", action="store_true", help="one batch at a time (no cross-batch pipelining)")
@@ -103,73 +128,76 @@ def main():
     weights = synthetic_weights(cfg, seed=0)
     model = GitCaptioner(cfg, weights, device=dev, max_batch=CLIPS_PER_GPU * args.coalesce, max_frames=FRAMES,
                          max_text_len=TOKENS, stop="never")
-    # rank r holds clips [r*16, (r+1)*16) of the global batch; inputs are resident in HBM
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    frames = torch.randn(CLIPS_PER_GPU, FRAMES, 3, cfg.image_size, cfg.image_size, generator=g).to(dev)
-    # The per-batch RCCL gather (int64[16,21] per rank) is issued asynchronously on RCCL's own stream into a small
-    # ring of output buffers and joined a few batches later: issued synchronously it would sit, stream-ordered, in
-    # front of every later submission while its kernel waits for a free CU on a saturated GPU.
-    NBUF = 8
-    gathered = [torch.empty((world * CLIPS_PER_GPU, TOKENS + 1), dtype=torch.int64, device=dev) for _ in range(NBUF)] if use_dist else None
-    works = []                                            # (work handle, output buffer, ids kept alive)
+    # rank r holds clips [r*16, (r+1)*16) of the global batch; inputs are resident in HBM.  Four distinct batches are
+    # rotated through so that no step re-reads the previous step's frames from a warm cache.
+    NIN = 4
+    g = torch.Generator(device="cpu").manual_seed(1234 + 16 * rank)
+    inputs = [torch.randn(CLIPS_PER_GPU, FRAMES, 3, cfg.image_size, cfg.image_size, generator=g).to(dev) for _ in range(NIN)]
+    # N > 1: the per-batch RCCL gather (int64[16,21] per rank) runs asynchronously into a ring of output buffers
+    # (gitcap/dist.py: CaptionGatherRing, covered on CPU by tests/test_dist_gloo.py)
+    ring = None
+    if use_dist:
+        from gitcap.dist import CaptionGatherRing
+        ring = CaptionGatherRing(world * CLIPS_PER_GPU, TOKENS + 1, dev, nbuf=8)
 
     def finish(ids, join=False):
-        if not use_dist:
+        if ring is None:
             return ids
-        buf = gathered[len(works) % NBUF]
-        if len(works) >= NBUF:                            # the buffer's previous gather (NBUF batches ago) is long done
-            works[len(works) - NBUF][0].wait()
-        w = dist.all_gather_into_tensor(buf, ids, async_op=True)   # rank-major: output row i is global clip i
-        works.append((w, buf, ids))
-        if join:
-            w.wait()
+        _, buf = ring.push(ids, join=join)
         return buf
 
-    def step():                                            # one batch, start to finish (gather joined: a caller waits for it)
-        return finish(model.greedy_decode(frames, max_len=TOKENS, stop="never"), join=True)
+    def step(i):                                           # one batch, start to finish (gather joined: a caller waits for it)
+        return finish(model.greedy_decode(inputs[i % NIN], max_len=TOKENS, stop="never"), join=True)
 
     def fence():
-        if use_dist:
-            for w, _, _ in works[-NBUF:]:
-                w.wait()                                  # every gather issued so far has completed after this + synchronize
-            dist.barrier()
+        if ring is not None:
+            ring.fence()                                   # every gather issued so far has completed, then barrier
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     fence()
     # K steps = K batches.  Default: three batches in flight (one image pass overlaps the token loops of
     # the batches before it, on the library's streams); every batch is submitted AND completed (ids gathered)
-    # inside the timed region.  --serial runs one batch at a time.
-    ev_sub = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev_done = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    if args.serial:
-        for i in range(args.steps):
-            ev_sub[i].record()
-            out = step()
-            ev_done[i].record()
-    else:
-        pending = []
-        for i in range(args.steps):
-            ev_sub[i].record()
-            pending.append((i, model.greedy_decode_async(frames, max_len=TOKENS, stop="never", coalesce=args.coalesce)))
-            if len(pending) == args.inflight * args.coalesce:
-                j, fut = pending.pop(0)
+    # inside the timed region.  --serial runs one batch at a time.  The region (barrier + synchronize on both sides,
+    # max over ranks) is repeated --repeats times and the median repeat is reported.
+    def timed_region():
+        ev_sub = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        ev_done = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        out = None
+        fence()
+        t0 = time.perf_counter()
+        if args.serial:
+            for i in range(args.steps):
+                ev_sub[i].record()
+                out = step(i)
+                ev_done[i].record()
+        else:
+            pending = []
+            for i in range(args.steps):
+                ev_sub[i].record()
+                pending.append((i, model.greedy_decode_async(inputs[i % NIN], max_len=TOKENS, stop="never", coalesce=args.coalesce)))
+                if len(pending) == args.inflight * args.coalesce:
+                    j, fut = pending.pop(0)
+                    out = finish(fut.result())
+                    ev_done[j].record()
+            for j, fut in pending:
                 out = finish(fut.result())
                 ev_done[j].record()
-        for j, fut in pending:
-            out = finish(fut.result())
-            ev_done[j].record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    lat = sorted(ev_sub[i].elapsed_time(ev_done[i]) for i in range(args.steps))   # submit -> ids ready, per batch
-    p50 = lat[len(lat) // 2]
-    if use_dist:
-        t = torch.tensor([elapsed, p50], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, p50 = float(t[0]), float(t[1])
-    assert out.shape == (world * CLIPS_PER_GPU, TOKENS + 1)
+        fence()
+        el = time.perf_counter() - t0
+        lat = sorted(ev_sub[i].elapsed_time(ev_done[i]) for i in range(args.steps))   # submit -> ids ready, per batch
+        p = lat[len(lat) // 2]
+        if use_dist:
+            t = torch.tensor([el, p], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el, p = float(t[0]), float(t[1])
+        assert out.shape == (world * CLIPS_PER_GPU, TOKENS + 1)
+        return el, p
+
+    regions = sorted(timed_region() for _ in range(max(1, args.repeats)))
+    elapsed, p50 = regions[len(regions) // 2]
+    region_ms = [round(r[0] * 1e3, 3) for r in regions]
 
     # ---- unpipelined reference point: one batch at a time (what a single real-time caller sees) ----
     serial = None
@@ -179,19 +207,42 @@ def main():
         fence()
         es[0].record()
         for i in range(ns):
-            step()
+            step(i)
             es[i + 1].record()
         fence()
         sl = sorted(es[i].elapsed_time(es[i + 1]) for i in range(ns))
         serial = {"captions_per_s_per_gpu": round(CLIPS_PER_GPU / (sum(sl) / ns * 1e-3), 1), "p50_latency_ms": round(sl[ns // 2], 3)}
+
+    # ---- decode phase (the 20-step token loop) against the HBM roofline: serial greedy(max_len=T) - greedy(max_len=1),
+    # i.e. T-1 token steps, scaled to T steps; algorithmic bytes of SURVEY.md par. 8(d) ----
+    def timed_greedy(max_len, n=8):
+        ts = []
+        for i in range(n + 2):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            model.greedy_decode(inputs[i % NIN], max_len=max_len, stop="never")
+            b.record()
+            torch.cuda.synchronize(dev)
+            ts.append(a.elapsed_time(b))
+        ts = sorted(ts[2:])
+        return ts[len(ts) // 2]
+    fence()
+    t_full, t_one = timed_greedy(TOKENS), timed_greedy(1)
+    loop_ms = (t_full - t_one) * TOKENS / (TOKENS - 1)
+    dbytes = decode_phase_bytes(cfg, CLIPS_PER_GPU, FRAMES, TOKENS)
+    decode = {"bound": "hbm", "what": f"token loop of one {CLIPS_PER_GPU} x {TOKENS} batch, serial", "ms": round(loop_ms, 3),
+              "us_per_token_step": round(loop_ms * 1e3 / TOKENS, 1), "algorithmic_gbytes": round(dbytes / 1e9, 3),
+              "achieved": round(dbytes / (loop_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": round(dbytes / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+              "image_pass_ms": round(t_one - loop_ms / TOKENS, 3)}
 
     # ---- per-kernel-class timing: HIP events recorded by the library on its launch stream ----
     roofline, breakdown = None, None
     if not args.no_profile:
         model.profile(True)
         nprof = min(args.steps, 5)
-        for _ in range(nprof):
-            model.greedy_decode(frames, max_len=TOKENS, stop="never")
+        for i in range(nprof):
+            model.greedy_decode(inputs[i % NIN], max_len=TOKENS, stop="never")
         torch.cuda.synchronize(dev)
         prof = model.profile_read()
         model.profile(False)
@@ -202,15 +253,19 @@ def main():
         achieved = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
         # HBM-side bytes per launch of this kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE,
         # WRITE_SIZE; gfx950 x2 fetch correction) recorded in profiles/: bench.py cannot profile itself
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                traffic = json.load(f).get("traffic_bytes_per_launch")
-            traffic_src = "profiles/r01_pmc_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --serial)"
+        # the newest profiles/rNN_pmc_gemm.json; it records the fingerprint of the kernel sources it was measured on
+        import glob
+        traffic, traffic_src, traffic_sha = None, None, None
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gemm.json")))
+        if pmcs:
+            with open(pmcs[-1]) as f:
+                pj = json.load(f)
+            traffic, traffic_sha = pj.get("traffic_bytes_per_launch"), pj.get("source_sha")
+            traffic_src = f"profiles/{os.path.basename(pmcs[-1])} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --serial)"
         roofline = {"bound": "mfma", "kernel": "gemm256_kernel", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": traffic_src,
+                    "traffic_source": traffic_src, "traffic_source_sha": traffic_sha, "library_source_sha": library_source_sha(),
+                    "traffic_stale": (traffic_sha != library_source_sha()) if traffic is not None else None,
                     "launches_per_step": gm["launches"] // nprof, "avg_launch_ms": round(avg_ms, 4),
                     "algorithmic_gflop_per_launch": round(gm["flops"] / max(1, gm["launches"]) / 1e9, 2)}
         def rate(cls, key, scale):
@@ -226,6 +281,9 @@ def main():
         }
         for v in roofline["classes"].values():
             v["frac"] = round(v["achieved"] / v["peak"], 4) if v["achieved"] else None
+    if roofline is None:
+        roofline = {}
+    roofline["decode_phase"] = decode
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -237,12 +295,13 @@ def main():
         line = {
             "metric": "captions/sec", "value": round(value, 2), "unit": "captions/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "repeats": len(regions), "region_ms_sorted": region_ms,
             "p50_latency_ms": round(p50, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2]: batch=16 6-frame 224x224 clips per GPU, GIT-base "
                                    "(ViT-B/16 + 6-layer decoder), 20-token greedy, EOS disabled",
                        "clips_per_gpu": CLIPS_PER_GPU, "frames": FRAMES, "tokens": TOKENS, "global_batch": world * CLIPS_PER_GPU,
-                       "parallelism": f"dp{world}", "batches_in_flight": 1 if args.serial else args.inflight * args.coalesce, "coalesce": args.coalesce, "collective": "all_gather(int64[16,21]) per step" if use_dist else "none"},
+                       "parallelism": f"dp{world}", "batches_in_flight": 1 if args.serial else args.inflight * args.coalesce, "coalesce": args.coalesce, "collective": "all_gather(int64[16,21]) per step" if use_dist else "none", "distinct_input_batches": NIN},
             "caption_mfma_frac": round(value / world * GFLOP_PER_CAPTION / 1e3 / MFMA_PEAK_TFLOPS, 4),
             "serial": serial, "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown,
         }

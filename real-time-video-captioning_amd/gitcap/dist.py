@@ -53,3 +53,58 @@ def gather_captions(ids: torch.Tensor, n_clips: int | None = None, group=None) -
     if all(hi - lo == bmax for lo, hi in sizes):
         return out
     return torch.cat([out[r * bmax: r * bmax + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], 0)
+
+
+class CaptionGatherRing:
+    """Asynchronous form of gather_captions for a stream of batches (what bench.py --gpus N runs every step).
+
+    Every batch's ids are all-gathered with ``async_op=True`` into one of ``nbuf`` output buffers and joined a few
+    batches later: issued synchronously the collective would sit, stream-ordered, in front of every later submission
+    while its kernel waits for a free CU on a saturated GPU.  ``push`` returns the output buffer (valid after the
+    returned work has been waited for, ``join=True`` waits at once); a buffer is reused only after the gather that
+    last wrote it has been waited for.  ``fence`` waits for every gather issued so far (then barrier).
+    Ragged shards are padded to the largest shard for the collective and trimmed in ``rows``.
+    """
+
+    def __init__(self, n_clips: int, L: int, device, nbuf: int = 8, group=None, dtype=torch.int64):
+        if not dist.is_initialized():
+            raise RuntimeError("CaptionGatherRing needs an initialised process group")
+        self.group, self.world, self.rank = group, dist.get_world_size(group), dist.get_rank(group)
+        self.sizes = [shard_range(n_clips, r, self.world) for r in range(self.world)]
+        self.bmax = max(hi - lo for lo, hi in self.sizes)
+        self.n_clips, self.L, self.nbuf = n_clips, L, nbuf
+        self.gloo = dist.get_backend(group) == "gloo"
+        self.bufs = [torch.empty((self.world * self.bmax, L), dtype=dtype, device=device) for _ in range(nbuf)]
+        self.works = []                                   # (work, buffer index, local ids kept alive)
+
+    def push(self, ids: torch.Tensor, join: bool = False):
+        lo, hi = self.sizes[self.rank]
+        if tuple(ids.shape) != (hi - lo, self.L):
+            raise ValueError(f"local block {tuple(ids.shape)} does not match shard_range {(hi - lo, self.L)}")
+        i = len(self.works) % self.nbuf
+        if len(self.works) >= self.nbuf:                  # the buffer's previous gather (nbuf batches ago)
+            self.works[len(self.works) - self.nbuf][0].wait()
+        pad = ids
+        if ids.shape[0] < self.bmax:
+            pad = torch.cat([ids, ids.new_zeros((self.bmax - ids.shape[0], self.L))], 0)
+        pad = pad.contiguous()
+        buf = self.bufs[i]
+        if self.gloo:
+            w = dist.all_gather(list(buf.view(self.world, self.bmax, self.L).unbind(0)), pad, group=self.group, async_op=True)
+        else:
+            w = dist.all_gather_into_tensor(buf, pad, group=self.group, async_op=True)   # rank-major: row i = global clip i
+        self.works.append((w, i, pad))
+        if join:
+            w.wait()
+        return w, buf
+
+    def rows(self, buf: torch.Tensor) -> torch.Tensor:
+        """Global clip order [n_clips, L] (drops the padding rows of ragged shards)."""
+        if all(hi - lo == self.bmax for lo, hi in self.sizes):
+            return buf
+        return torch.cat([buf[r * self.bmax: r * self.bmax + (hi - lo)] for r, (lo, hi) in enumerate(self.sizes)], 0)
+
+    def fence(self):
+        for w, _, _ in self.works[-self.nbuf:]:
+            w.wait()
+        dist.barrier(group=self.group)

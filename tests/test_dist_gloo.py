@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from gitcap.dist import gather_captions, shard_range
+from gitcap.dist import CaptionGatherRing, gather_captions, shard_range
 
 
 def _worker(rank, world, port, n_clips, L, q):
@@ -43,3 +43,54 @@ def test_two_rank_gather_is_rank_major(n_clips):
     expect = [[101] + list(range(c + 1, c + L)) for c in range(n_clips)]
     for r in range(world):
         assert got[r] == expect
+
+
+def _ring_worker(rank, world, port, n_clips, L, nbatch, nbuf, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(n_clips, rank, world)
+        ring = CaptionGatherRing(n_clips, L, "cpu", nbuf=nbuf)
+        outs = []
+        for b in range(nbatch):                           # batch b: the row of global clip c is [101, 1000*b + c + 1, ...]
+            ids = torch.zeros((hi - lo, L), dtype=torch.long)
+            for i, c in enumerate(range(lo, hi)):
+                ids[i] = torch.arange(1000 * b + c, 1000 * b + c + L)
+                ids[i, 0] = 101
+            w, buf = ring.push(ids, join=(b % 3 == 0))    # some joined at once, most a few batches later
+            outs.append((w, buf))
+            if len(outs) > 2:                             # consume two batches behind, like bench.py's pipeline
+                w0, buf0 = outs[-3]
+                w0.wait()
+                q.put((rank, b - 2, ring.rows(buf0).tolist()))
+        ring.fence()
+        for b in (nbatch - 2, nbatch - 1):
+            q.put((rank, b, ring.rows(outs[b][1]).tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_clips", [32, 5])
+def test_two_rank_gather_ring(n_clips):
+    """The asynchronous gather ring bench.py uses for N > 1 (>= 2 x nbuf batches, ragged last shard when
+    n_clips = 5): every batch arrives complete and in global clip order on every rank."""
+    world, L, nbuf = 2, 6, 3
+    nbatch = 2 * nbuf + 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30100 + (os.getpid() % 500) + n_clips
+    procs = [ctx.Process(target=_ring_worker, args=(r, world, port, n_clips, L, nbatch, nbuf, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world * nbatch):
+        rank, b, rows = q.get(timeout=120)
+        got[(rank, b)] = rows
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for b in range(nbatch):
+        expect = [[101] + list(range(1000 * b + c + 1, 1000 * b + c + L)) for c in range(n_clips)]
+        for r in range(world):
+            assert got[(r, b)] == expect, (r, b)

@@ -2,7 +2,9 @@
 #   python tools/pmc_tables.py gpurun_out/prof_e profiles/r01_e
 # FETCH_SIZE / WRITE_SIZE are KiB per dispatch; FETCH_SIZE is doubled (gfx950 correction, MI355X_MICROARCH.md HBM);
 # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs.
-import csv, glob, json, sys, collections
+import csv, glob, json, os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import library_source_sha   # fingerprint of the kernel sources these counters were measured on
 src, dst = sys.argv[1], sys.argv[2]
 def load(sub):
     f = glob.glob('%s/%s/**/*counter_collection.csv' % (src, sub), recursive=True)[0]
@@ -36,7 +38,7 @@ g = [k for k in fe if k.startswith('gemm256_kernel')]
 cat = lambda d, c: [v for k in g for v in d[k][c]]
 fetch, write = mean(cat(fe, 'FETCH_SIZE')), mean(cat(wr, 'WRITE_SIZE'))
 busy, gui = mean(cat(sq, 'SQ_VALU_MFMA_BUSY_CYCLES')), mean(cat(sq, 'GRBM_GUI_ACTIVE'))
-js = {"kernel": "gemm256_kernel (all epilogues), bench.py --serial, 4 steps", "launches_sampled": len(cat(fe, 'FETCH_SIZE')),
+js = {"kernel": "gemm256_kernel (all epilogues), bench.py --serial, 4 steps", "source_sha": library_source_sha(), "launches_sampled": len(cat(fe, 'FETCH_SIZE')),
       "FETCH_SIZE_KB_avg_raw": round(fetch, 1), "WRITE_SIZE_KB_avg": round(write, 1), "gfx950_fetch_correction": 2.0,
       "traffic_bytes_per_launch": int((2.0 * fetch + write) * 1024), "mfma_busy_cycles_avg": int(busy),
       "grbm_gui_active_sum8xcd_avg": int(gui),
