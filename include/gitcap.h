@@ -118,6 +118,17 @@ int gitcap_text_forward(gitcap_t* h, const int64_t* ids, int ld_ids, int rows, i
                         int t0, int T, float* logits_out, int all_positions,
                         int64_t* argmax_out, int ld_argmax, void* stream);
 
+/* Replaces: the third return of GenerativeImageTextModel.forward_one_custom (hidden_states, stacked per layer)
+ *                                                         src/models/model.py:419-424, :747-760
+ * Opt-in (it costs a copy of every row after every layer, and the image rows of the LAST decoder layer, which are
+ * otherwise never computed: only their K/V are needed).  While enabled, gitcap_encode / gitcap_set_visual and a
+ * gitcap_text_forward with t0 = 0 keep the decoder stack's input and the output of each of its layers;
+ * gitcap_hidden_states_read writes them as out[b][e][s][:], device fp32 [B][dec_layers + 1][S_img + T][dec_width]
+ * (e = 0: projected image tokens ; text embeddings, e = l: output of layer l; s over [image ; text]).
+ * Synchronous entry points only (not the pipelined submissions). */
+int gitcap_hidden_states_enable(gitcap_t* h, int enable);
+int gitcap_hidden_states_read(gitcap_t* h, int B, int S_img, int T, float* out, void* stream);
+
 /* Replaces: StudentCandidateV1.greedy_decode(src, max_len) src/models/model.py:156-187
  *           as called by src/real_time_inference.py:58 and src/inference.py:51
  * Encodes, prefills with CLS and runs max_len greedy steps entirely on the device.
@@ -188,8 +199,7 @@ int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launche
 /* Kernel-level test hooks (tests/test_kernels_gpu.py, tools/gemm_bench.py): run ONE kernel on
  * caller-owned device buffers.  gemm: out[m][n] = sum_k A[m][k]*W[n][k] (+epilogue `epi` of
  * csrc/kernels.h: 0 bias->bf16, 1 bias+QuickGELU->bf16, 2 bias+GELU->bf16, 3 bias+resid->f32,
- * 4 bias->f32); A [M][K] bf16, W [N][K] bf16, M % 128 == 0; tile = 128, 256 (the product kernel),
- * 257 (persistent variant) or 258 (two-workgroups-per-CU variant; both measured experiments). */
+ * 4 bias->f32); A [M][K] bf16, W [N][K] bf16, M % 128 == 0; tile = 128 or 256 (the two product kernels). */
 int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float* resid, void* out,
                     int M, int N, int K, int epi, int tile, void* stream);
 /* attn_full: qkv [G*S][3*H*64] bf16 -> ctx [G*S][H*64] bf16 */

@@ -102,7 +102,12 @@ def gen_tiny(out_dir):
         visual = hf_visual(model, frames)
         proj = model.git.visual_projection(visual)
         gids, last16, ti, tv = hf_greedy(model, frames, 8, cfg.cls_token_id)
-        np.savez_compressed(os.path.join(out_dir, f"hf_tiny_F{F}.npz"),
+        # per-layer hidden states over [image ; text] (what forward_one_custom stacks, model.py:419-424): the
+        # encoder's input followed by the output of each of its layers, L+1 entries of [B, S_img + T, D]
+        pv = frames if model.config.num_image_with_embedding is not None else frames[:, 0]
+        hs = model(input_ids=ids, pixel_values=pv, use_cache=False, output_hidden_states=True).hidden_states
+        hidden = torch.stack([h.float() for h in hs], 0)
+        np.savez_compressed(os.path.join(out_dir, f"hf_tiny_F{F}.npz"), hidden=hidden.detach().numpy(),
                             prefix_ids=ids.numpy(), logits=logits.numpy(), visual=visual.numpy(),
                             projected=proj.detach().numpy(), greedy_ids=gids.numpy(),
                             greedy_top_ids=ti.numpy(), greedy_top_vals=tv.numpy(),

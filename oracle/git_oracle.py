@@ -159,8 +159,8 @@ class GitOracle:
         x = torch.cat([memory, self.embed_text(ids)], dim=1)
         rows = torch.arange(S_img + T)
         klimit = torch.where(rows < S_img, torch.full_like(rows, S_img), rows + 1)
-        hidden = []
-        for i in range(cfg.dec_layers):
+        hidden = [x]                  # L+1 entries [B, S_img+T, D]: the stack's input, then each layer's output
+        for i in range(cfg.dec_layers):   # (what forward_one_custom stacks as hidden_states, model.py:419-424)
             k, v = self._kv(i, x)
             x = self._dec_layer(i, x, k, v, klimit)
             hidden.append(x)

@@ -14,6 +14,10 @@
 #include <vector>
 
 #define GITCAP_ABI_VERSION 1
+// (tools/build_diag.py redefines this to reach the experimental tile kernels of tools/experiments/)
+#ifndef GITCAP_DBG_GEMM_DISPATCH
+#define GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, s) ((tile) == 256 ? launch_gemm256(a, epi, s) : launch_gemm(a, epi, s))
+#endif
 
 namespace {
 
@@ -44,6 +48,10 @@ struct gitcap {
     std::map<std::string, float*> wscale;          // e4m3 storage: per-row scales of the GEMM weights
     bool finalized = false, fp8 = false;
     bf16_t* wstage = nullptr;                       // e4m3 storage: bf16 staging panel of the big-tile GEMMs
+    // opt-in export of the decoder's per-layer hidden states (gitcap_hidden_states_enable): [L+1][rows][D] fp32
+    bool want_hidden = false;
+    float *hid_img = nullptr, *hid_txt = nullptr;
+    int hid_T = 0;
     int64_t weight_bytes = 0;
 
     // derived sizes
@@ -112,9 +120,6 @@ struct gitcap {
 namespace {
 
 std::string g_create_err;
-// persistent-tile GEMM (gemm256p.hip) is an opt-in experiment: +2-5 % on multi-round shapes, slower on
-// the fp32-residual epilogue (DESIGN.md "What did not work")
-const bool g_persist = getenv("GITCAP_GEMM_PERSIST") && atoi(getenv("GITCAP_GEMM_PERSIST")) != 0;
 // Number of decode streams the four slots share (slot i decodes on stream i % n).  HIP multiplexes streams onto
 // GPU_MAX_HW_QUEUES (default 4) hardware queues; with one stream per slot the throughput depended on which streams
 // happened to share a queue (1073-1723 captions/s over 1..8 queues, 1514 as soon as an RCCL communicator added its
@@ -131,7 +136,7 @@ const int g_small_tiles = getenv("GITCAP_GEMM_SMALL_TILES") ? atoi(getenv("GITCA
 // (tests/test_kernels_gpu.py), so the choice only affects speed.
 hipError_t launch_gemm_auto(const GemmArgs& a, int epi, hipStream_t s) {
     if (!gemm256_ok(a) || (a.M >> 8) * (a.N >> 8) < g_small_tiles) return launch_gemm(a, epi, s);
-    return g_persist ? launch_gemm256p(a, epi, s) : launch_gemm256(a, epi, s);
+    return launch_gemm256(a, epi, s);
 }
 
 // OCP e4m3fn code of x, or -1 when x is not exactly representable (bias 7, 3 mantissa bits, max 448, no infinities)
@@ -325,10 +330,15 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
     if ((rc = gemm(h, s, EPI_BIAS_F32, h->hb, Dv, h->vproj_w, h->vproj_b, Mp, D, Dv, h->tmp, D))) return rc;
     if ((rc = ln(h, s, h->tmp, D, h->vproj_lnw, h->vproj_lnb, c.proj_ln_eps, rows, D, h->x, D, h->hb, D))) return rc;
     const size_t kv_layer = (size_t)h->Mi * 3 * D;
+    const bool hid = h->want_hidden && h->cur_slot == 0;     // hidden-state export: synchronous path only
+    auto keep = [&](int entry) -> hipError_t {
+        return hid ? hipMemcpyAsync(h->hid_img + (size_t)entry * h->Mi * D, h->x, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, s) : hipSuccess;
+    };
+    HIP_OK(h, keep(0));
     for (int l = 0; l < c.dec_layers; ++l) {
         const DecLayer& L = h->dec[l];
         bf16_t* kv = h->kv_img + (size_t)l * kv_layer;
-        if (l + 1 < c.dec_layers) {
+        if (l + 1 < c.dec_layers || hid) {
             if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, D, L.qkvw, L.qkvb, Mp, 3 * D, D, kv, 3 * D))) return rc;
             {
                 ProfScope ps(h, GITCAP_PROF_ATTN_FULL, s, 4.0 * B * c.dec_heads * (double)S * S * 64, 0.0);
@@ -339,6 +349,7 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
             if ((rc = gemm(h, s, EPI_BIAS_GELU_BF16, h->hb, D, L.fc1w, L.fc1b, Mp, c.dec_ffn, D, h->ffn, c.dec_ffn))) return rc;
             if ((rc = gemm(h, s, EPI_BIAS_RESID_F32, h->ffn, c.dec_ffn, L.fc2w, L.fc2b, Mp, D, c.dec_ffn, h->tmp, D, h->x, D))) return rc;
             if ((rc = ln(h, s, h->tmp, D, L.ln2w, L.ln2b, c.dec_ln_eps, rows, D, h->x, D, h->hb, D))) return rc;
+            HIP_OK(h, keep(l + 1));
         } else {
             // last layer: image rows are only ever read as keys/values -> K,V projections only
             if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, D, L.qkvw.rows_from(D, D), L.qkvb + D, Mp, 2 * D, D, kv + D, 3 * D))) return rc;
@@ -362,6 +373,11 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     int rc;
     const size_t kvi_layer = (size_t)h->Mi * 3 * D, kvt_layer = (size_t)h->R * h->Tmax * 3 * D;
     const int ks_f = skinny_ksplit(c.dec_ffn);
+    const bool hid = h->want_hidden && h->cur_slot == 0 && t0 == 0;    // hidden-state export: a whole prefix, synchronous path
+    auto keep_txt = [&](int entry) -> hipError_t {                       // xs = the text rows' input of layer `entry`
+        return hid ? hipMemcpyAsync(h->hid_txt + (size_t)entry * h->Mt * D, h->xs, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s) : hipSuccess;
+    };
+    if (hid) h->hid_T = T;
     // Per layer 5 launches: [text embedding | reduce of the previous layer's FC2 slabs + LayerNorm], q|k|v projection
     // straight into the text K/V cache, attention + output dense + LayerNorm (txtblock.hip), FC1 + GELU, FC2 as split-K
     // partial slabs.
@@ -375,6 +391,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
             const DecLayer& P = h->dec[l - 1];
             if ((rc = ln_reduce(h, s, h->slabs, ks_f, P.fc2b, h->xs, P.ln2w, P.ln2b, c.dec_ln_eps, M, D, h->xs, h->xsb))) return rc;
         }
+        HIP_OK(h, keep_txt(l));
         if ((rc = skinny(h, s, SK_BIAS_BF16, h->xsb, D, L.qkvw, L.qkvb, M, 3 * D, D, kvt, 3 * D, T, h->Tmax, t0))) return rc;
         {
             TxtBlockArgs ta{};
@@ -393,6 +410,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     {   // the last layer's FC2 reduce + bias + residual + LayerNorm
         const DecLayer& P = h->dec[c.dec_layers - 1];
         if ((rc = ln_reduce(h, s, h->slabs, ks_f, P.fc2b, h->xs, P.ln2w, P.ln2b, c.dec_ln_eps, M, D, h->xs, h->xsb))) return rc;
+        HIP_OK(h, keep_txt(c.dec_layers));
     }
     if (!logits_out && !argmax_out) return 0;
     // vocabulary head (+ arg-max partials per 16-column tile, reduced by argmax_final)
@@ -931,9 +949,8 @@ int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float
     a.A = (const bf16_t*)A; a.lda = K; a.W = (const bf16_t*)W; a.bias = bias; a.M = M; a.N = N; a.K = K;
     a.out = out; a.ldo = N; a.resid = resid; a.ldr = N;
     if (epi < 0 || epi > EPI_BIAS_F32) return GITCAP_ERR_ARG;
-    hipError_t e = (tile == 258) ? launch_gemm2b(a, epi, (hipStream_t)stream)
-                 : (tile == 257) ? launch_gemm256p(a, epi, (hipStream_t)stream)
-                 : (tile == 256) ? launch_gemm256(a, epi, (hipStream_t)stream) : launch_gemm(a, epi, (hipStream_t)stream);
+    if (tile != 128 && tile != 256) return GITCAP_ERR_ARG;
+    hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, (hipStream_t)stream);
     return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
 }
 
@@ -945,6 +962,33 @@ int gitcap_dbg_layernorm(const float* x, const float* gamma, const float* beta, 
                          float* out_f32, void* out_bf16, void* stream) {
     LnArgs a{x, D, gamma, beta, eps, rows, D, out_f32, D, (bf16_t*)out_bf16, D, nullptr, 1, 1};
     return launch_layernorm(a, (hipStream_t)stream) == hipSuccess ? 0 : GITCAP_ERR_HIP;
+}
+
+int gitcap_hidden_states_enable(gitcap_t* h, int enable) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "hidden_states_enable: null handle");
+    GUARD(h);
+    select_slot(h, 0);
+    if (enable && !h->hid_img) {
+        const size_t n = (size_t)h->c.dec_layers + 1;
+        int rc = ws_alloc(h, &h->hid_img, n * h->Mi * h->D);
+        rc = rc ? rc : ws_alloc(h, &h->hid_txt, n * h->Mt * h->D);
+        if (rc) return rc;
+    }
+    h->want_hidden = enable != 0;
+    h->have_image = false;          // the image rows of the last layer are only computed while this is on
+    return 0;
+}
+
+int gitcap_hidden_states_read(gitcap_t* h, int B, int S_img, int T, float* out, void* stream) {
+    if (!h || !out) return fail(h, GITCAP_ERR_ARG, "hidden_states_read: null argument");
+    GUARD(h);
+    select_slot(h, 0);
+    if (!h->want_hidden || !h->have_image) return fail(h, GITCAP_ERR_STATE, "hidden_states_read: enable, encode and run a prefix (t0 = 0) first");
+    if (B != h->cur_B || S_img != h->cur_S || T != h->hid_T || T <= 0)
+        return fail(h, GITCAP_ERR_ARG, "hidden_states_read: B / S_img / T differ from the last encode + text_forward");
+    HIP_OK(h, launch_gather_hidden(h->hid_img, h->hid_txt, out, h->c.dec_layers + 1, B, S_img, T, h->D, (size_t)h->Mi * h->D,
+                                   (size_t)h->Mt * h->D, (hipStream_t)stream));
+    return 0;
 }
 
 int gitcap_set_weight_storage(gitcap_t* h, int storage) {

@@ -24,9 +24,6 @@ struct GemmArgs {
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);      // 128x128 tile (any M%128, N%128)
 bool gemm256_ok(const GemmArgs& a);
 hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);   // 256x256 tile, 8-wave ping-pong
-hipError_t launch_gemm256p(const GemmArgs& a, int epi, hipStream_t s);  // same, persistent over tiles
-bool gemm2b_ok(const GemmArgs& a);
-hipError_t launch_gemm2b(const GemmArgs& a, int epi, hipStream_t s);    // 256(n)x128(m) tile, 4 waves, two workgroups per CU
 
 // ---- skinny GEMMs (text rows; M = a few 16-row tiles): weight streaming, one wave per tile ----
 enum SkinnyEpi { SK_BIAS_BF16 = 0, SK_BIAS_GELU_BF16 = 1, SK_BIAS_RELU_BF16 = 2, SK_BIAS_F32 = 3 };
@@ -111,6 +108,9 @@ hipError_t launch_layernorm(const LnArgs& a, hipStream_t s);
 hipError_t launch_im2col(const float* frames, bf16_t* patches, int nf, int img, int p, int Kp, hipStream_t s);
 // x[frame*N + 0][:] = cls + pos[0]
 hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int nf, int N, int D, hipStream_t s);
+// out[b][e][s][:] = s < S_img ? img[e][b*S_img + s][:] : txt[e][b*T + s - S_img][:]   (e < n_entries; fp32 rows of D)
+hipError_t launch_gather_hidden(const float* img, const float* txt, float* out, int n_entries, int B, int S_img, int T, int D,
+                                size_t img_entry_stride, size_t txt_entry_stride, hipStream_t s);
 // f32 -> bf16 copy
 hipError_t launch_cast_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s);
 // e4m3 weight rows [rows][K] (+ per-row power-of-two scale) -> bf16 [rows][K] (exact); K % 16 == 0

@@ -108,6 +108,18 @@ __global__ void cast_bf16_kernel(const float* __restrict__ in, bf16_t* __restric
     *(uint2*)(out + i * 4) = w;
 }
 
+// per-layer hidden states -> caller layout [B][entries][S_img + T][D]; one 256-thread block per output row
+__global__ __launch_bounds__(256) void gather_hidden_kernel(const float* __restrict__ img, const float* __restrict__ txt,
+                                                            float* __restrict__ out, int n_entries, int S_img, int T, int D,
+                                                            size_t img_stride, size_t txt_stride) {
+    const int S = S_img + T;
+    const size_t row = blockIdx.x;                       // ((b * n_entries) + e) * S + s
+    const int s = (int)(row % S), e = (int)((row / S) % n_entries), b = (int)(row / ((size_t)S * n_entries));
+    const float* src = s < S_img ? img + e * img_stride + ((size_t)b * S_img + s) * D
+                                 : txt + e * txt_stride + ((size_t)b * T + (s - S_img)) * D;
+    for (int c = threadIdx.x * 4; c < D; c += 1024) *(f32x4*)(out + row * D + c) = *(const f32x4*)(src + c);
+}
+
 // e4m3 weight panel -> bf16 staging panel for the big-tile GEMMs (16 values per thread: 16-B read, 32-B write)
 __global__ __launch_bounds__(256) void dequant_fp8_kernel(const unsigned char* __restrict__ w8, const float* __restrict__ scale,
                                                           bf16_t* __restrict__ out, int K, int64_t n16) {
@@ -581,6 +593,15 @@ hipError_t launch_cast_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t
     if (n % 4) return hipErrorInvalidValue;
     const int64_t n4 = n / 4;
     hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, in, out, n4);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_hidden(const float* img, const float* txt, float* out, int n_entries, int B, int S_img, int T, int D,
+                                size_t img_entry_stride, size_t txt_entry_stride, hipStream_t s) {
+    if (B <= 0 || n_entries <= 0 || S_img <= 0 || T <= 0 || D % 4) return hipErrorInvalidValue;
+    const size_t rows = (size_t)B * n_entries * (S_img + T);
+    hipLaunchKernelGGL(gather_hidden_kernel, dim3((unsigned)rows), dim3(256), 0, s, img, txt, out, n_entries, S_img, T, D,
+                       img_entry_stride, txt_entry_stride);
     return hipGetLastError();
 }
 

@@ -20,6 +20,8 @@ SYMBOLS = {
     "gitcap_last_error": (c_char_p, [c_void_p]),
     "gitcap_load_tensor": (c_int, [c_void_p, c_char_p, c_void_p, POINTER(c_int64), c_int]),
     "gitcap_finalize_weights": (c_int, [c_void_p]),
+    "gitcap_hidden_states_enable": (c_int, [c_void_p, c_int]),
+    "gitcap_hidden_states_read": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gitcap_set_weight_storage": (c_int, [c_void_p, c_int]),
     "gitcap_weight_bytes": (c_int, [c_void_p, POINTER(c_int64)]),
     "gitcap_encode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -324,13 +324,29 @@ class GitCaptioner(nn.Module):
         return out
 
     @torch.no_grad()
-    def forward_output_logits(self, x: torch.Tensor, y: torch.Tensor):
-        """Teacher API (model.py:747-760): per clip lists of logits [1,T,V] and visual features
-        [1,F*N,Dv]; computed as ONE batch instead of the reference's clip-by-clip loop (:752-759).
-        Per-layer hidden states (third list) are not exported by the kernels: returned empty."""
-        _, vis = self.forward_image_enc(x)
-        logits = self.forward_decoder(y, vis)
-        return [l[None] for l in logits], [v[None] for v in vis], []
+    def forward_output_logits(self, x: torch.Tensor, y: torch.Tensor, output_hidden_states: bool = False):
+        """Teacher API (model.py:747-760): per clip lists of logits [1,T,V], visual features [1,F*N,Dv] and hidden
+        states; computed as ONE batch instead of the reference's clip-by-clip loop (:752-759).
+        The third list (model.py:419-424: the decoder stack's per-layer hidden states over [image ; text], stacked
+        to [dec_layers + 1, F*N + T, D] per clip) is opt-in: the reference's only caller discards it (:896) and it costs
+        a copy of every row after every layer plus the image rows of the last layer.  Empty unless requested."""
+        if not output_hidden_states:
+            _, vis = self.forward_image_enc(x)
+            logits = self.forward_decoder(y, vis)
+            return [l[None] for l in logits], [v[None] for v in vis], []
+        self._drain()
+        self._call("gitcap_hidden_states_enable", 1)
+        try:
+            _, vis = self.forward_image_enc(x)
+            logits = self.forward_decoder(y, vis)
+            B, S_img, T = vis.shape[0], vis.shape[1], logits.shape[1]
+            hid = torch.empty((B, self.cfg.dec_layers + 1, S_img + T, self.cfg.dec_width), dtype=torch.float32, device=self._dev)
+            with torch.cuda.device(self._dev):
+                self._call("gitcap_hidden_states_read", B, S_img, T, ctypes.c_void_p(hid.data_ptr()), self._stream())
+        finally:
+            self._call("gitcap_hidden_states_enable", 0)
+            self._last_memory = None
+        return [l[None] for l in logits], [v[None] for v in vis], [h for h in hid]
 
     @torch.no_grad()
     def greedy_decode(self, src: torch.Tensor, max_len: int = 10, stop: Optional[str] = None) -> torch.Tensor:

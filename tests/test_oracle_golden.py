@@ -24,6 +24,10 @@ def test_tiny_oracle_matches_hf(golden_dir, F):
     assert np.abs(mem.numpy() - g["projected"]).max() < 1e-4
     logits = orc.decoder_full(mem, torch.from_numpy(g["prefix_ids"]))
     assert np.abs(logits.numpy() - g["logits"]).max() < 2e-4           # fp32 vs fp32, logit std ~4
+    # per-layer hidden states over [image ; text] (model.py:419-424): the stack's input + each layer's output
+    _, hidden = orc.decoder_full(mem, torch.from_numpy(g["prefix_ids"]), return_hidden=True)
+    assert len(hidden) == cfg.dec_layers + 1 and g["hidden"].shape[0] == cfg.dec_layers + 1
+    assert np.abs(torch.stack(hidden, 0).numpy() - g["hidden"]).max() < 2e-4
     for use_cache in (True, False):                                     # exact KV cache == full recompute
         ids = orc.greedy_decode(fr, 8, stop="never", use_cache=use_cache)
         assert np.array_equal(ids.numpy(), g["greedy_ids"])

@@ -444,3 +444,27 @@ def test_device_beam_search_base_size(captioner_cls):
     for b in range(2):
         if not torch.equal(dev["predictions"][b].cpu(), want[0][b]):
             assert abs(float(dev["logprobs"][b].cpu() - want[1][b])) < 0.02
+
+
+def test_forward_output_logits_hidden_states(captioner_cls, golden_dir):
+    """Third return of forward_output_logits (model.py:419-424, :747-760): per clip the decoder stack's input and the
+    output of each layer over [image ; text], [dec_layers + 1, S_img + T, D]; against the bf16-emulating oracle and the
+    transformers fixture (output_hidden_states=True)."""
+    cfg = git_tiny(2)
+    w = synthetic_weights(cfg, 0)
+    g = np.load(os.path.join(golden_dir, "hf_tiny_F2.npz"))
+    fr = make_frames(2, 2, cfg.image_size, int(g["frame_seed"]))
+    ids = torch.from_numpy(g["prefix_ids"])
+    m = captioner_cls(cfg, w, max_batch=2, max_text_len=8)
+    logits, vis, hid = m.forward_output_logits(fr, ids, output_hidden_states=True)
+    assert len(hid) == 2 and tuple(hid[0].shape) == (cfg.dec_layers + 1, 2 * cfg.tokens_per_frame + ids.shape[1], cfg.dec_width)
+    got = torch.stack([h.cpu() for h in hid], 1)                          # [L+1, B, S, D] like the fixture
+    emul = GitOracle(cfg, w, emulate_bf16=True)
+    _, mem = emul.forward_image_enc(fr)
+    _, want = emul.decoder_full(mem, ids, return_hidden=True)
+    assert (got - torch.stack(want, 0)).abs().max() < 0.06, float((got - torch.stack(want, 0)).abs().max())
+    assert np.abs(got.numpy() - g["hidden"]).max() < 0.12                 # fp32 transformers fixture (hidden std ~1)
+    # the default call is unchanged (no hidden states, same logits), also right after an exporting call
+    l2, _, h2 = m.forward_output_logits(fr, ids)
+    assert h2 == [] and torch.equal(torch.cat(l2), torch.cat(logits))
+    assert torch.equal(m.greedy_decode(fr, max_len=6, stop="never"), captioner_cls(cfg, w, max_batch=2, max_text_len=8).greedy_decode(fr, max_len=6, stop="never"))
