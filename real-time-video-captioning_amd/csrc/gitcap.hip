@@ -531,7 +531,7 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     if (!rc) {   // select slot 0
         gitcap::Slot& n = h->slots[0];
         h->sep_cnt = n.sep_cnt; h->xs = n.xs; h->slabs = n.slabs; h->part = n.part; h->row_cnt = n.row_cnt;
-        h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
+            h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
         h->xsb = n.xsb; h->fs = n.fs; h->kv_txt = n.kv_txt; h->kv_txt2 = n.kv_txt2;
     }
     if (!rc) {
