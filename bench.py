@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is repeated; the median repeat is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumented pass")
+    ap.add_argument("--plain", action="store_true", help="only warm-up + the timed region (for rocprofv3 runs: every pass in the trace is one full step)")
     ap.add_argument("--serial", action="store_true", help="one batch at a time (no cross-batch pipelining)")
     ap.add_argument("--inflight", type=int, default=3, choices=(2, 3, 4),
                     help="submissions in flight when pipelined (3: same throughput as 4, lower latency)")
@@ -201,7 +202,7 @@ def main():
 
     # ---- unpipelined reference point: one batch at a time (what a single real-time caller sees) ----
     serial = None
-    if not args.serial:
+    if not args.serial and not args.plain:
         ns = min(args.steps, 10)
         es = [torch.cuda.Event(enable_timing=True) for _ in range(ns + 1)]
         fence()
@@ -226,19 +227,21 @@ def main():
             ts.append(a.elapsed_time(b))
         ts = sorted(ts[2:])
         return ts[len(ts) // 2]
-    fence()
-    t_full, t_one = timed_greedy(TOKENS), timed_greedy(1)
-    loop_ms = (t_full - t_one) * TOKENS / (TOKENS - 1)
-    dbytes = decode_phase_bytes(cfg, CLIPS_PER_GPU, FRAMES, TOKENS)
-    decode = {"bound": "hbm", "what": f"token loop of one {CLIPS_PER_GPU} x {TOKENS} batch, serial", "ms": round(loop_ms, 3),
-              "us_per_token_step": round(loop_ms * 1e3 / TOKENS, 1), "algorithmic_gbytes": round(dbytes / 1e9, 3),
-              "achieved": round(dbytes / (loop_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-              "frac": round(dbytes / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-              "image_pass_ms": round(t_one - loop_ms / TOKENS, 3)}
+    decode = None
+    if not args.plain:
+        fence()
+        t_full, t_one = timed_greedy(TOKENS), timed_greedy(1)
+        loop_ms = (t_full - t_one) * TOKENS / (TOKENS - 1)
+        dbytes = decode_phase_bytes(cfg, CLIPS_PER_GPU, FRAMES, TOKENS)
+        decode = {"bound": "hbm", "what": f"token loop of one {CLIPS_PER_GPU} x {TOKENS} batch, serial", "ms": round(loop_ms, 3),
+                  "us_per_token_step": round(loop_ms * 1e3 / TOKENS, 1), "algorithmic_gbytes": round(dbytes / 1e9, 3),
+                  "achieved": round(dbytes / (loop_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": round(dbytes / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                  "image_pass_ms": round(t_one - loop_ms / TOKENS, 3)}
 
     # ---- per-kernel-class timing: HIP events recorded by the library on its launch stream ----
     roofline, breakdown = None, None
-    if not args.no_profile:
+    if not args.no_profile and not args.plain:
         model.profile(True)
         nprof = min(args.steps, 5)
         for i in range(nprof):
@@ -281,9 +284,9 @@ def main():
         }
         for v in roofline["classes"].values():
             v["frac"] = round(v["achieved"] / v["peak"], 4) if v["achieved"] else None
-    if roofline is None:
-        roofline = {}
-    roofline["decode_phase"] = decode
+    if decode is not None:
+        roofline = roofline or {}
+        roofline["decode_phase"] = decode
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

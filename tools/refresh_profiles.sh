@@ -7,12 +7,12 @@ tag=${1:-x}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile"
+B="python3 bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --plain"
 rocprofv3 --kernel-trace --stats -d $out/stats_pipelined --output-format csv -- $B > $out/bench_pipelined.json 2> $out/stats_pipelined.err
 echo "stats pipelined done"
 rocprofv3 --kernel-trace --stats -d $out/stats_serial --output-format csv -- $B --serial > $out/bench_serial.json 2> $out/stats_serial.err
 echo "stats serial done"
-P="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --serial"
+P="python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --plain --serial"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch --output-format csv -- $P > /dev/null 2> $out/pmc_fetch.err
 echo "pmc fetch done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write --output-format csv -- $P > /dev/null 2> $out/pmc_write.err
