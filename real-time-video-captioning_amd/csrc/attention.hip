@@ -24,6 +24,14 @@ constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// phase stamps: only in the diagnostic build of tools/probe/attn_probe.hip (the product kernel has none)
+#ifdef ATTN_STAMPS
+__device__ unsigned long long* g_attn_stamps;
+#define ATTN_STAMP(i) do { if ((threadIdx.x & 63) == 0 && g_attn_stamps) g_attn_stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ATTN_STAMP(i) do {} while (0)
+#endif
+
 template <int NST>
 __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict__ qkv,
                                                         bf16_t* __restrict__ ctx, int S, int H, int G, int nqb) {
@@ -107,6 +115,7 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
     // s_barrier then (a) publishes every wave's pieces of tile t and (b) proves every wave is done
     // with tile t-1, whose stage the next DMA overwrites.
     const int ntiles = (S + 63) >> 6;
+    ATTN_STAMP(0);
 #pragma unroll
     for (int i = 0; i < NST - 1; ++i)
         if (i < ntiles) stage(i, i * 64);
@@ -119,6 +128,7 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + NST - 1 < ntiles) stage((t + NST - 1) % NST, (t + NST - 1) * 64);
+        if (t < 6) ATTN_STAMP(1 + 2 * t);          // barrier passed: tile t is in LDS
         if (!wave_active) continue;
         const char* sb = lds + (t % NST) * 16384;
         const int key0 = t * 64;
@@ -138,10 +148,10 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
             for (int ks = 0; ks < 4; ++ks)
                 s_acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][ks], qf[ks], s_acc[kt], 0, 0, 0);
         }
-        // ---- V^T fragments: requested now, consumed after the softmax (latency hidden under VALU) ---
+        // ---- V^T fragments of the first 32 keys: requested now, consumed after the softmax; the second 32 keys'
+        //      fragments are requested when the first half's MFMAs have been issued (16 fewer live registers) -----
         bf16x4 vlo[2][2][2], vhi[2][2][2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        auto load_v = [&](int kt) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -150,6 +160,8 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
                     vlo[kt][s2][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(vp));
                     vhi[kt][s2][dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(vp + 8 * 64));
                 }
+        };
+        load_v(0);
         // ---- mask the ragged last tile (wave-uniform branch) ---------------------------------
         if (key0 + 64 > S) {
 #pragma unroll
@@ -190,7 +202,8 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
 
         // ---- O^T += V^T . P^T -----------------------------------------------------------------
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < 2; ++kt) {
+            if (kt == 0) load_v(1);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 // 8 probabilities -> one bf16x8 B fragment (4 x v_cvt_pk_bf16_f32)
@@ -205,7 +218,10 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
                     o_acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o_acc[dt], 0, 0, 0);
                 }
             }
+        }
+        if (t < 6) ATTN_STAMP(2 + 2 * t);          // tile t consumed (issue side)
     }
+    ATTN_STAMP(13);
 
     if (wave_active) {
         const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -224,6 +240,7 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
                 }
         }
     }
+    ATTN_STAMP(14);
 }
 
 }  // namespace
