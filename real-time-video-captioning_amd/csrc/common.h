@@ -21,14 +21,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 __device__ __forceinline__ float bf2f(bf16_t h) {
     return __builtin_bit_cast(float, (unsigned)h << 16);
 }
-__device__ __forceinline__ unsigned pack_bf2(float lo, float hi);
-// 8 OCP e4m3 bytes -> one bf16 MFMA fragment.  Exact: every e4m3 value is a bf16 value (v_cvt_pk_f32_fp8, then pack).
-__device__ __forceinline__ bf16x8 fp8x8_to_bf16x8(uint2 q) {
-    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.x, true);
-    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)q.y, true);
+// 8 OCP e4m3 bytes x one power-of-two scale -> one bf16 MFMA fragment: four v_cvt_scalef32_pk_bf16_fp8 (gfx950).
+// Exact: e4m3 x 2^k is a bf16 value, so the fragment is bit for bit the bf16-stored weight.
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16x8(uint2 q, float scale) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-    const u32x4_t r = {pack_bf2(a[0], a[1]), pack_bf2(b[0], b[1]), pack_bf2(c[0], c[1]), pack_bf2(d[0], d[1])};
+    const bf16x2_t a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.x, scale, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.x, scale, true);
+    const bf16x2_t c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.y, scale, false), d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(q.y, scale, true);
+    const u32x4_t r = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d)};
     return __builtin_bit_cast(bf16x8, r);
 }
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {

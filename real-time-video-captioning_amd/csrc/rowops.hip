@@ -128,15 +128,9 @@ __global__ __launch_bounds__(256) void dequant_fp8_kernel(const unsigned char* _
     const int64_t e = i * 16;
     const float sc = scale[e / K];
     const uint4 q = *(const uint4*)(w8 + e);
-    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    const unsigned w[4] = {q.x, q.y, q.z, q.w};
-    unsigned o[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[j], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[j], true);
-        o[2 * j] = pack_bf2(a[0] * sc, a[1] * sc);
-        o[2 * j + 1] = pack_bf2(b[0] * sc, b[1] * sc);
-    }
+    const bf16x8 lo = fp8x8_to_bf16x8(make_uint2(q.x, q.y), sc), hi = fp8x8_to_bf16x8(make_uint2(q.z, q.w), sc);
+    const uint4 o4l = __builtin_bit_cast(uint4, lo), o4h = __builtin_bit_cast(uint4, hi);
+    const unsigned o[8] = {o4l.x, o4l.y, o4l.z, o4l.w, o4h.x, o4h.y, o4h.z, o4h.w};
     *(uint4*)(out + e) = make_uint4(o[0], o[1], o[2], o[3]);
     *(uint4*)(out + e + 8) = make_uint4(o[4], o[5], o[6], o[7]);
 }

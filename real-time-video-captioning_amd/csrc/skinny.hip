@@ -21,16 +21,17 @@
 namespace {
 
 // weight fragments of one 16-row tile, K32 k-steps.  FP8: e4m3 bytes (8 per lane and k-step, half the stream),
-// expanded to bf16 in registers; the per-row power-of-two scale is applied to the accumulator (exact).
+// expanded in registers to bf16 times the row's power-of-two scale (exact: the bf16-stored weight bit for bit).
 template <int K32, bool FP8>
-__device__ __forceinline__ void load_wfrags(const void* W, size_t row, int K, int kofs, bf16x8 (&wf)[K32]) {
+__device__ __forceinline__ void load_wfrags(const void* W, const float* wscale, size_t row, int K, int kofs, bf16x8 (&wf)[K32]) {
     if (FP8) {
         const unsigned char* wp = (const unsigned char*)W + row * K + kofs;
+        const float sc = wscale[row];
         uint2 raw[K32];
 #pragma unroll
         for (int k = 0; k < K32; ++k) raw[k] = *(const uint2*)(wp + k * 32);
 #pragma unroll
-        for (int k = 0; k < K32; ++k) wf[k] = fp8x8_to_bf16x8(raw[k]);
+        for (int k = 0; k < K32; ++k) wf[k] = fp8x8_to_bf16x8(raw[k], sc);
     } else {
         const bf16_t* wp = (const bf16_t*)W + row * K + kofs;
 #pragma unroll
@@ -44,15 +45,12 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
     const int frow = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * 16;
     bf16x8 wf[K32];
-    load_wfrags<K32, FP8>(a.W, (size_t)(n0 + frow), a.K, fq * 8, wf);
+    load_wfrags<K32, FP8>(a.W, a.wscale, (size_t)(n0 + frow), a.K, fq * 8, wf);
 
     const int n = n0 + fq * 4;
-    float bias[4], wsc[4];
+    float bias[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        bias[r] = (a.bias && n + r < a.N) ? a.bias[n + r] : 0.f;
-        wsc[r] = FP8 ? a.wscale[n + r] : 1.f;                    // (weight rows are padded to 16: always in range)
-    }
+    for (int r = 0; r < 4; ++r) bias[r] = (a.bias && n + r < a.N) ? a.bias[n + r] : 0.f;
 
     const int mtiles = (a.M + 15) >> 4;
     for (int mt = 0; mt < mtiles; ++mt) {
@@ -69,7 +67,7 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
         // lane holds out[m][n .. n+3]
         float y[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[r] = (FP8 ? acc[r] * wsc[r] : acc[r]) + bias[r];
+        for (int r = 0; r < 4; ++r) y[r] = acc[r] + bias[r];
         if (EPI == SK_BIAS_GELU_BF16) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) y[r] = erf_gelu(y[r]);
@@ -128,10 +126,8 @@ __global__ __launch_bounds__(64) void skinny_splitk_kernel(SkinnyArgs a) {
     const int n0 = blockIdx.x * 16, ks = blockIdx.y;
     const int kbeg = ks * K32 * 32;
     bf16x8 wf[K32];
-    load_wfrags<K32, FP8>(a.W, (size_t)(n0 + frow), a.K, kbeg + fq * 8, wf);
+    load_wfrags<K32, FP8>(a.W, a.wscale, (size_t)(n0 + frow), a.K, kbeg + fq * 8, wf);
     const int n = n0 + fq * 4;
-    f32x4 wsc = f32x4{1.f, 1.f, 1.f, 1.f};
-    if (FP8) wsc = *(const f32x4*)(a.wscale + n);
     float* slab = (float*)a.out + (size_t)ks * a.M * a.ldo;
     const int mtiles = (a.M + 15) >> 4;
     for (int mt = 0; mt < mtiles; ++mt) {
@@ -145,7 +141,7 @@ __global__ __launch_bounds__(64) void skinny_splitk_kernel(SkinnyArgs a) {
             const bf16x8 xf = *(const bf16x8*)(xp + k * 32);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k], xf, acc, 0, 0, 0);
         }
-        if (mvalid) *(f32x4*)(slab + (size_t)m * a.ldo + n) = FP8 ? acc * wsc : acc;
+        if (mvalid) *(f32x4*)(slab + (size_t)m * a.ldo + n) = acc;
     }
 }
 

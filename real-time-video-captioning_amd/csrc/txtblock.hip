@@ -275,10 +275,11 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
             const int t = wid + 16 * i;
             if (t < D / 16) {
                 bf16x8 w0, w1;
-                if (FP8) {
+                if (FP8) {      // e4m3 x the row's power-of-two scale = the bf16-stored weight, bit for bit
                     const unsigned* q = (const unsigned*)(mypre + (4 * i) * 256) + lane;
-                    w0 = fp8x8_to_bf16x8(make_uint2(q[0], q[64]));
-                    w1 = fp8x8_to_bf16x8(make_uint2(q[128], q[192]));
+                    const float sc = a.aoscale[t * 16 + frow];
+                    w0 = fp8x8_to_bf16x8(make_uint2(q[0], q[64]), sc);
+                    w1 = fp8x8_to_bf16x8(make_uint2(q[128], q[192]), sc);
                 } else {
                     w0 = *(const bf16x8*)(mypre + (2 * i) * 1024 + lane * 16);
                     w1 = *(const bf16x8*)(mypre + (2 * i + 1) * 1024 + lane * 16);
@@ -288,8 +289,7 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, c1, acc, 0, 0, 0);
                 if (frow == 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)      // e4m3 weights: the row's power-of-two scale goes on the accumulator (exact)
-                        __hip_atomic_store(pp + t * 16 + fq * 4 + e, FP8 ? acc[e] * a.aoscale[t * 16 + fq * 4 + e] : acc[e], RLX_AGENT);
+                    for (int e = 0; e < 4; ++e) __hip_atomic_store(pp + t * 16 + fq * 4 + e, acc[e], RLX_AGENT);
                 }
             }
         }
