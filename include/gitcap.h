@@ -80,8 +80,8 @@ int gitcap_finalize_weights(gitcap_t* h);
  * GITCAP_W_FP8_E4M3: every GEMM weight is kept as OCP e4m3 bytes + one power-of-two fp32 scale per output row, half
  * the bytes of bf16.  The values passed to gitcap_load_tensor must already be e4m3 x 2^k (weight-only quantisation is
  * the caller's choice: gitcap.weights.quantize_weights_fp8); anything else is refused, nothing is rounded silently.
- * The weight-streaming text kernels read the e4m3 bytes and expand them in registers; the big-tile GEMMs of the image
- * pass read each panel through a bf16 staging buffer.  Arithmetic is unchanged (bf16 MFMA, fp32 accumulate): results
+ * The weight-streaming text kernels read the e4m3 bytes and expand them in registers (times the row scale: exactly the
+ * bf16 value); the big-tile GEMMs of the image pass read each panel through a bf16 staging buffer.  Arithmetic is unchanged (bf16 MFMA, fp32 accumulate): results
  * are bitwise those of bf16 storage of the same values. */
 typedef enum { GITCAP_W_BF16 = 0, GITCAP_W_FP8_E4M3 = 1 } gitcap_weight_storage;
 int gitcap_set_weight_storage(gitcap_t* h, int storage);
