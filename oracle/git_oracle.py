@@ -167,6 +167,37 @@ class GitOracle:
         logits = self._lin(x[:, S_img:], "head")
         return (logits, hidden) if return_hidden else logits
 
+    # the image half once, any number of text prefixes against it (what a search loop over a no-cache `step` needs:
+    # decoder_full recomputes the whole image prefix for every row of every step)
+    def image_kv(self, memory: torch.Tensor):
+        """Per-layer K/V of the image rows [B,H,S_img,64] (text independent: image rows never see text)."""
+        cfg = self.cfg
+        S_img = memory.shape[1]
+        x, kv = memory, []
+        full = torch.full((S_img,), S_img)
+        for i in range(cfg.dec_layers):
+            k, v = self._kv(i, x)
+            kv.append((k, v))
+            if i + 1 < cfg.dec_layers:
+                x = self._dec_layer(i, x, k, v, full)
+        return kv
+
+    def decoder_text(self, image_kv, ids: torch.Tensor, clip_of_row: torch.Tensor | None = None) -> torch.Tensor:
+        """Logits [R,T,V] of the text rows for prefixes ids [R,T] given image_kv (from image_kv()); row r uses the image
+        K/V of clip clip_of_row[r] (default r).  Same arithmetic as decoder_full restricted to the text rows."""
+        cfg = self.cfg
+        R, T = ids.shape
+        sel = torch.arange(R) if clip_of_row is None else clip_of_row
+        S_img = image_kv[0][0].shape[2]
+        klimit = S_img + torch.arange(T) + 1
+        x = self.embed_text(ids)
+        for i in range(cfg.dec_layers):
+            kt, vt = self._kv(i, x)
+            k = torch.cat([image_kv[i][0][sel], kt], dim=2)
+            v = torch.cat([image_kv[i][1][sel], vt], dim=2)
+            x = self._dec_layer(i, x, k, v, klimit)
+        return self._lin(x, "head")
+
     # exact KV-cached variant (image K/V are text independent, so the cache is exact)
     def prefill(self, memory: torch.Tensor, ids: torch.Tensor):
         cfg = self.cfg

@@ -33,6 +33,22 @@ def test_tiny_oracle_matches_hf(golden_dir, F):
         assert np.array_equal(ids.numpy(), g["greedy_ids"])
 
 
+def test_text_rows_against_cached_image_kv_equal_full_pass():
+    """decoder_text (image K/V computed once, text rows only) == decoder_full on the same prefixes, also with
+    several rows (beams) sharing one clip's image K/V."""
+    cfg = git_tiny(2)
+    orc = GitOracle(cfg, synthetic_weights(cfg, 0))
+    fr = make_frames(2, 2, cfg.image_size, 9)
+    _, mem = orc.forward_image_enc(fr)
+    ids = torch.tensor([[101, 5, 9, 33, 2], [101, 77, 3, 150, 8]])
+    kv = orc.image_kv(mem)
+    assert (orc.decoder_text(kv, ids) - orc.decoder_full(mem, ids)).abs().max() < 1e-5
+    clip = torch.tensor([0, 0, 1, 1, 1])
+    ids5 = torch.tensor([[101, 5, 9], [101, 7, 9], [101, 77, 3], [101, 1, 1], [101, 2, 190]])
+    want = orc.decoder_full(mem[clip], ids5)
+    assert (orc.decoder_text(kv, ids5, clip) - want).abs().max() < 1e-5
+
+
 def test_tiny_kv_cache_equals_full_recompute_logits():
     cfg = git_tiny(2)
     orc = GitOracle(cfg, synthetic_weights(cfg, 0))

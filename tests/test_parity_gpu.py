@@ -399,18 +399,19 @@ def test_config4_real_shape_fp8_beam(captioner_cls):
     emul = GitOracle(cfg, wq, emulate_bf16=True)
     with torch.no_grad():
         _, mem = emul.forward_image_enc(fr)
+        ikv = emul.image_kv(mem)                  # the image half once; every search step reruns the text rows only
     _, vis = m.forward_image_enc(fr)
     assert vis.shape == (1, 10 * 257, 1024)
     ids = torch.tensor([[101, 2023, 2003, 1037, 3899]])
     lg = m.forward_decoder(ids, vis).cpu()
     with torch.no_grad():
-        l_e = emul.decoder_full(mem, ids)
+        l_e = emul.decoder_text(ikv, ids)
     assert (lg - l_e).abs().max() < LOGIT_TOL_EMUL * 1.5, float((lg - l_e).abs().max())
     out = m.infer(fr, beam_size=4, max_steps=15, length_penalty=0.6, on_device=True)
 
     def step(t):
         with torch.no_grad():
-            return emul.decoder_full(mem.repeat_interleave(4, dim=0), t)[:, -1]
+            return emul.decoder_text(ikv, t, torch.zeros(t.shape[0], dtype=torch.long))[:, -1]
     want = oracle_beam_search(torch.full((1, 1), cfg.cls_token_id), step, eos_index=cfg.sep_token_id, max_steps=15,
                               beam_size=4, length_penalty=0.6)
     assert out["predictions"].shape == (1, 15)
@@ -434,10 +435,11 @@ def test_device_beam_search_base_size(captioner_cls):
     emul = GitOracle(cfg, w, emulate_bf16=True)
     with torch.no_grad():
         _, mem = emul.forward_image_enc(fr)
+        ikv = emul.image_kv(mem)
 
     def step(t):
         with torch.no_grad():
-            return emul.decoder_full(mem.repeat_interleave(4, dim=0), t)[:, -1]
+            return emul.decoder_text(ikv, t, torch.arange(2).repeat_interleave(4))[:, -1]
     want = oracle_beam_search(torch.full((2, 1), cfg.cls_token_id), step, eos_index=cfg.sep_token_id, max_steps=10,
                               beam_size=4, length_penalty=0.6)
     assert torch.allclose(dev["logprobs"].cpu(), want[1], atol=0.05), (dev["logprobs"], want[1])
