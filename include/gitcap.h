@@ -145,6 +145,14 @@ int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, i
  * Stateless (no handle). */
 int gitcap_preprocess(const uint8_t* frames_hwc_bgr, int nf, int H, int W, float* out_nchw, int crop, void* stream);
 
+/* The two calls above for RAW camera frames (what src/real_time_inference.py:39-57 has before its transform):
+ * frames_hwc_bgr device uint8 [B][F][H][W][3].  The transform of gitcap_preprocess (crop = image_size) is fused with
+ * the patch gather of the encoder (SURVEY.md par. 8f.1): the bf16 patch rows are written directly, no fp32 frame tensor
+ * exists.  Results are bitwise those of gitcap_preprocess followed by gitcap_encode / gitcap_greedy. */
+int gitcap_encode_raw(gitcap_t* h, const uint8_t* frames_hwc_bgr, int B, int F, int H, int W, float* visual_out, void* stream);
+int gitcap_greedy_raw(gitcap_t* h, const uint8_t* frames_hwc_bgr, int B, int F, int H, int W, int max_len, int stop,
+                      int64_t* ids_out, int32_t* steps_out, void* stream);
+
 /* Replaces: F.log_softmax(scores) + beam_scores, view(B, beams*V), torch.topk(2*beams)
  *                                                         src/models/model.py:557-565
  * logits: device fp32 [B*beams][ld]; beam_scores: device fp32 [B*beams]; outputs: device

@@ -435,18 +435,19 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     return 0;
 }
 
-int check_frames(gitcap* h, const float* frames, int B, int F) {
+int check_frames(gitcap* h, const void* frames, int B, int F, bool raw = false) {
     if (!h->finalized) return fail(h, GITCAP_ERR_STATE, "weights not finalized");
     if (!frames || B <= 0 || F <= 0) return fail(h, GITCAP_ERR_ARG, "encode: bad arguments");
     if (B > h->c.max_batch || F > h->c.max_frames) return fail(h, GITCAP_ERR_ARG, "encode: B/F exceed the sizes the handle was created for");
     if (h->c.num_frames > 0 && F > h->c.num_frames) return fail(h, GITCAP_ERR_ARG, "encode: more frames than temporal embeddings");
-    if (((uintptr_t)frames & 15) != 0) return fail(h, GITCAP_ERR_ARG, "encode: frames must be 16-byte aligned");
+    if (!raw && ((uintptr_t)frames & 15) != 0) return fail(h, GITCAP_ERR_ARG, "encode: frames must be 16-byte aligned");
     return 0;
 }
 
 }  // namespace
 
-static int encode_impl(gitcap* h, const float* frames, int B, int F, float* visual_out, hipStream_t stream);
+struct FrameSrc { const float* f32; const uint8_t* u8; int H, W; };     // fp32 NCHW (CLIP-normalised) or raw uint8 HWC BGR
+static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out, hipStream_t stream);
 
 extern "C" {
 
@@ -706,11 +707,11 @@ int gitcap_encode(gitcap_t* h, const float* frames, int B, int F, float* visual_
     GUARD(h);
     select_slot(h, 0);
     HIP_OK(h, join_async(h, (hipStream_t)stream));
-    return encode_impl(h, frames, B, F, visual_out, (hipStream_t)stream);
+    return encode_impl(h, FrameSrc{frames, nullptr, 0, 0}, B, F, visual_out, (hipStream_t)stream);
 }
 
-static int encode_impl(gitcap* h, const float* frames, int B, int F, float* visual_out, hipStream_t stream) {
-    int rc = check_frames(h, frames, B, F);
+static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out, hipStream_t stream) {
+    int rc = src.u8 ? check_frames(h, src.u8, B, F, true) : check_frames(h, src.f32, B, F);
     if (rc) return rc;
     hipStream_t s = stream;
     const gitcap_config& c = h->c;
@@ -719,7 +720,13 @@ static int encode_impl(gitcap* h, const float* frames, int B, int F, float* visu
     h->have_image = false;
 
     // patchify (conv k = stride = p, no bias) + CLS + position embedding, then ln_pre
-    HIP_OK(h, launch_im2col(frames, h->patches, nf, c.image_size, c.patch_size, h->Kp, s));
+    if (src.u8) {     // raw camera frames: resize + crop + BGR->RGB + normalise fused with the patch gather (no fp32 frames)
+        hipError_t e = launch_preprocess_patches(src.u8, h->patches, nf, src.H, src.W, c.image_size, c.patch_size, h->Kp, s);
+        if (e == hipErrorInvalidValue) return fail(h, GITCAP_ERR_ARG, "encode_raw: frames smaller than the crop, or bad sizes");
+        HIP_OK(h, e);
+    } else {
+        HIP_OK(h, launch_im2col(src.f32, h->patches, nf, c.image_size, c.patch_size, h->Kp, s));
+    }
     {
         hipError_t e;
         const bf16_t* Wb = stage_weight(h, s, h->patch_w, Dv, h->Kp, &e);
@@ -811,7 +818,27 @@ int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, i
     if (rc) return rc;
     select_slot(h, 0);
     HIP_OK(h, join_async(h, (hipStream_t)stream));
-    if ((rc = encode_impl(h, frames, B, F, nullptr, (hipStream_t)stream))) return rc;
+    if ((rc = encode_impl(h, FrameSrc{frames, nullptr, 0, 0}, B, F, nullptr, (hipStream_t)stream))) return rc;
+    return greedy_text_loop(h, B, max_len, stop, ids_out, steps_out, (hipStream_t)stream);
+}
+
+int gitcap_encode_raw(gitcap_t* h, const uint8_t* frames_hwc_bgr, int B, int F, int H, int W, float* visual_out, void* stream) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "encode_raw: null handle");
+    GUARD(h);
+    select_slot(h, 0);
+    HIP_OK(h, join_async(h, (hipStream_t)stream));
+    return encode_impl(h, FrameSrc{nullptr, frames_hwc_bgr, H, W}, B, F, visual_out, (hipStream_t)stream);
+}
+
+int gitcap_greedy_raw(gitcap_t* h, const uint8_t* frames_hwc_bgr, int B, int F, int H, int W, int max_len, int stop,
+                      int64_t* ids_out, int32_t* steps_out, void* stream) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "greedy_raw: null handle");
+    GUARD(h);
+    int rc = greedy_check(h, max_len, stop, ids_out);
+    if (rc) return rc;
+    select_slot(h, 0);
+    HIP_OK(h, join_async(h, (hipStream_t)stream));
+    if ((rc = encode_impl(h, FrameSrc{nullptr, frames_hwc_bgr, H, W}, B, F, nullptr, (hipStream_t)stream))) return rc;
     return greedy_text_loop(h, B, max_len, stop, ids_out, steps_out, (hipStream_t)stream);
 }
 
@@ -829,7 +856,7 @@ int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max
     HIP_OK(h, hipStreamWaitEvent(h->s_enc, sl.ev_in, 0));
     // ... and once the previous user of this slot's image K/V (two submissions ago) has finished decoding
     if (sl.used) HIP_OK(h, hipStreamWaitEvent(h->s_enc, sl.ev_dec, 0));
-    if ((rc = encode_impl(h, frames, B, F, nullptr, h->s_enc))) return rc;
+    if ((rc = encode_impl(h, FrameSrc{frames, nullptr, 0, 0}, B, F, nullptr, h->s_enc))) return rc;
     HIP_OK(h, hipEventRecord(sl.ev_enc, h->s_enc));
     HIP_OK(h, hipStreamWaitEvent(sl.s_txt, sl.ev_enc, 0));
     if ((rc = greedy_text_loop(h, B, max_len, stop, ids_out, steps_out, sl.s_txt))) return rc;
@@ -863,7 +890,7 @@ int gitcap_beam_search(gitcap_t* h, const float* frames, int B, int F, int beams
     hipStream_t s = (hipStream_t)stream;
     select_slot(h, 0);
     HIP_OK(h, join_async(h, s));
-    int rc = encode_impl(h, frames, B, F, nullptr, s);
+    int rc = encode_impl(h, FrameSrc{frames, nullptr, 0, 0}, B, F, nullptr, s);
     if (rc) return rc;
     const int rows = B * beams, K = beams * per_node_beam_size, V = h->c.vocab_size, L = max_steps;
     HIP_OK(h, launch_beam_init(h->beam, B, beams, L, h->c.cls_token_id, s));

@@ -132,6 +132,8 @@ hipError_t launch_beam_topk(const float* logits, int ld, const float* beam_score
                             float* out_scores, int* out_idx, hipStream_t s);
 // uint8 HWC BGR frames [nf][H][W][3] -> CLIP-normalised fp32 NCHW [nf][3][crop][crop] (bicubic resize + centre crop)
 hipError_t launch_preprocess(const unsigned char* in, float* out, int nf, int H, int W, int crop, hipStream_t s);
+// the same transform fused with the patch gather: -> bf16 patch rows [nf*G*G][Kp] (layout of launch_im2col)
+hipError_t launch_preprocess_patches(const unsigned char* in, bf16_t* patches, int nf, int H, int W, int crop, int p, int Kp, hipStream_t s);
 // device-resident beam search state + one bookkeeping step per decoder step (rowops.hip)
 struct BeamBuffers {
     int64_t *ids0, *ids1, *words, *hyp_ids;

@@ -29,6 +29,8 @@ SYMBOLS = {
     "gitcap_text_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "gitcap_greedy": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gitcap_encode_raw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "gitcap_greedy_raw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gitcap_greedy_submit": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
     "gitcap_greedy_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "gitcap_preprocess": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -240,6 +240,20 @@ class GitCaptioner(nn.Module):
             x = x.clone()
         return x
 
+    def _raw_frames(self, x: torch.Tensor) -> torch.Tensor:
+        """uint8 BGR camera frames [B,F,H,W,3] (OpenCV layout, real_time_inference.py:39) or [F,H,W,3] for one clip."""
+        if x.dim() == 4:
+            x = x.unsqueeze(0)
+        if x.dim() != 5 or x.shape[-1] != 3:
+            raise ValueError(f"expected uint8 frames [B,F,H,W,3], got {tuple(x.shape)}")
+        if x.shape[0] == 0:
+            raise ValueError("empty batch")
+        if x.shape[1] > self.max_frames:
+            raise ValueError(f"{x.shape[1]} frames per clip > max_frames={self.max_frames}")
+        if min(x.shape[2], x.shape[3]) < 1:
+            raise ValueError("empty frames")
+        return x.to(device=self._dev).contiguous()
+
     def _ids(self, y: torch.Tensor) -> torch.Tensor:
         return y.to(device=self._dev, dtype=torch.int64).contiguous()
 
@@ -250,13 +264,18 @@ class GitCaptioner(nn.Module):
         frames concatenated along tokens, model.py:378-382).  Also leaves the decoder's image K/V
         in the handle."""
         self._drain()
-        fr = self._frames(x)
+        raw = x.dtype == torch.uint8
+        fr = self._raw_frames(x) if raw else self._frames(x)
         B, F = fr.shape[:2]
         if B > self.max_batch:
             raise ValueError(f"batch {B} > max_batch={self.max_batch} (use greedy_decode for automatic chunking)")
         vis = torch.empty((B, F * self.cfg.tokens_per_frame, self.cfg.enc_width), dtype=torch.float32, device=self._dev)
         with torch.cuda.device(self._dev):
-            self._call("gitcap_encode", ctypes.c_void_p(fr.data_ptr()), B, F, ctypes.c_void_p(vis.data_ptr()), self._stream())
+            if raw:
+                self._call("gitcap_encode_raw", ctypes.c_void_p(fr.data_ptr()), B, F, fr.shape[2], fr.shape[3],
+                           ctypes.c_void_p(vis.data_ptr()), self._stream())
+            else:
+                self._call("gitcap_encode", ctypes.c_void_p(fr.data_ptr()), B, F, ctypes.c_void_p(vis.data_ptr()), self._stream())
         self._remember_memory(vis)
         return [], vis
 
@@ -359,7 +378,8 @@ class GitCaptioner(nn.Module):
         if max_len > self.max_text_len:
             raise ValueError(f"max_len {max_len} > max_text_len={self.max_text_len} the handle was created for")
         self._drain()
-        fr = self._frames(src)
+        raw = src.dtype == torch.uint8            # camera frames [B,F,H,W,3] uint8 BGR: transform fused into the patch gather
+        fr = self._raw_frames(src) if raw else self._frames(src)
         B, F = fr.shape[:2]
         outs, steps_all = [], []
         with torch.cuda.device(self._dev):
@@ -367,8 +387,13 @@ class GitCaptioner(nn.Module):
                 chunk = fr[b0:b0 + self.max_batch]
                 ids = torch.empty((chunk.shape[0], max_len + 1), dtype=torch.int64, device=self._dev)
                 steps = torch.zeros((1,), dtype=torch.int32, device=self._dev)
-                self._call("gitcap_greedy", ctypes.c_void_p(chunk.data_ptr()), chunk.shape[0], F, max_len, mode,
-                           ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(steps.data_ptr()), self._stream())
+                if raw:
+                    self._call("gitcap_greedy_raw", ctypes.c_void_p(chunk.data_ptr()), chunk.shape[0], F, chunk.shape[2],
+                               chunk.shape[3], max_len, mode, ctypes.c_void_p(ids.data_ptr()),
+                               ctypes.c_void_p(steps.data_ptr()), self._stream())
+                else:
+                    self._call("gitcap_greedy", ctypes.c_void_p(chunk.data_ptr()), chunk.shape[0], F, max_len, mode,
+                               ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(steps.data_ptr()), self._stream())
                 outs.append(ids)
                 steps_all.append(steps)
         self._last_memory = None

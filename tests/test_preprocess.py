@@ -66,3 +66,13 @@ def test_raw_frames_to_caption():
     assert first == a.shape[1] or float(gap[0, first - 1]) > 0, (a, b)
     with pytest.raises(ValueError):
         preprocess_frames(torch.zeros(4, 4, 3))
+    # raw uint8 frames straight into the model: the transform fused with the patch gather (gitcap_greedy_raw /
+    # gitcap_encode_raw) gives BITWISE the result of preprocess_frames followed by the fp32 entry points
+    c = m.greedy_decode(raw, max_len=10, stop="never").cpu()
+    assert torch.equal(c, a)
+    _, v_raw = m.forward_image_enc(raw)
+    _, v_two = m.forward_image_enc(dev_in)
+    assert torch.equal(v_raw, v_two)
+    small = torch.randint(0, 256, (1, 6, 100, 300, 3), dtype=torch.uint8, generator=g)      # shorter side < crop: upsampled
+    assert torch.equal(m.greedy_decode(small, max_len=4, stop="never").cpu(),
+                       m.greedy_decode(preprocess_frames(small), max_len=4, stop="never").cpu())
