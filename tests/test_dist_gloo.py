@@ -94,3 +94,31 @@ def test_two_rank_gather_ring(n_clips):
         expect = [[101] + list(range(1000 * b + c + 1, 1000 * b + c + L)) for c in range(n_clips)]
         for r in range(world):
             assert got[(r, b)] == expect, (r, b)
+
+
+@pytest.mark.gpu
+def test_gather_ring_on_rccl_single_rank():
+    """The same ring over RCCL ("nccl" backend) with device tensors: one rank on the GPU box (the multi-rank runs are
+    the driver's); every batch must come back intact after more pushes than ring buffers."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    port = 31200 + (os.getpid() % 500)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        ring = CaptionGatherRing(16, 21, torch.device("cuda", 0), nbuf=3)
+        outs = []
+        for b in range(8):
+            ids = (torch.arange(16 * 21, device="cuda").view(16, 21) + 1000 * b).long()
+            w, buf = ring.push(ids, join=(b % 4 == 0))
+            outs.append((w, buf, ids))
+            if len(outs) > 2:
+                w0, buf0, ids0 = outs[-3]
+                w0.wait()
+                torch.cuda.synchronize()
+                assert torch.equal(ring.rows(buf0), ids0)
+        ring.fence()
+        torch.cuda.synchronize()
+        assert torch.equal(ring.rows(outs[-1][1]), outs[-1][2])
+        assert torch.equal(gather_captions(outs[-1][2], 16), outs[-1][2])
+    finally:
+        dist.destroy_process_group()
