@@ -205,6 +205,19 @@ def test_errors_are_loud(captioner_cls):
     bare = captioner_cls(cfg, None, max_batch=1, max_text_len=4)
     with pytest.raises(GitcapError):                          # weights never loaded
         bare.greedy_decode(make_frames(1, 2, cfg.image_size, 0), max_len=2)
+    # round-2 entry points: call order and arguments are checked, nothing fails silently
+    import ctypes
+    with pytest.raises(GitcapError, match="before the first"):          # storage must be chosen before any tensor is loaded
+        m._call("gitcap_set_weight_storage", 1)
+    buf = torch.empty(64, device="cuda")
+    with pytest.raises(GitcapError, match="enable"):                    # hidden states were never requested
+        m._call("gitcap_hidden_states_read", 1, 2 * cfg.tokens_per_frame, 3, ctypes.c_void_p(buf.data_ptr()), m._stream())
+    with pytest.raises(ValueError):                                     # the device search refuses a beam underflow set-up
+        captioner_cls(cfg, synthetic_weights(cfg, 0), max_batch=1, max_text_len=6, max_beams=2).infer(
+            make_frames(1, 2, cfg.image_size, 0), beam_size=2, max_steps=4, per_node_beam_size=1, on_device=True)
+    with pytest.raises(GitcapError):                                    # raw frames smaller than... zero-sized
+        m._call("gitcap_greedy_raw", ctypes.c_void_p(buf.data_ptr()), 1, 2, 0, 0, 2, 0, ctypes.c_void_p(buf.data_ptr()), None, m._stream())
+    assert m.weight_bytes() > 0 and m.workspace_bytes() > m.weight_bytes()
 
 
 def test_pipelined_submit_matches_synchronous(captioner_cls):
