@@ -210,6 +210,13 @@ int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launche
  * 4 bias->f32); A [M][K] bf16, W [N][K] bf16, M % 128 == 0; tile = 128 or 256 (the two product kernels). */
 int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float* resid, void* out,
                     int M, int N, int K, int epi, int tile, void* stream);
+/* GEMM + bias [+ resid] followed by LayerNorm of the output rows (N = 768 or 1024).  post = 0: out_f32 = x = A W^T + bias +
+ * resid, out_bf16 = LN(x) (pre-LN block); post = 1: out_f32 = out_bf16 = LN(x), resid may be NULL (post-LN block).
+ * fused = 1: inside the 256x256 kernel (the tiles of a 256-row block exchange segment statistics); fused = 0: the `tile`
+ * kernel, then the row kernel.  Both produce the same bits (csrc/ln_canon.h). */
+int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const float* resid, const float* gamma,
+                       const float* beta, float eps, float* out_f32, void* out_bf16, int M, int N, int K, int post,
+                       int fused, int tile, void* stream);
 /* attn_full: qkv [G*S][3*H*64] bf16 -> ctx [G*S][H*64] bf16 */
 int gitcap_dbg_attn_full(const void* qkv, void* ctx, int G, int S, int H, void* stream);
 /* layernorm: x fp32 [rows][D] -> out_f32 / out_bf16 (either may be NULL) */

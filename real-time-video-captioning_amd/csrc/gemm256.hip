@@ -252,7 +252,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     if (grp == 0) BARRIER();                       // matches group 1's extra leading barrier
 
     // ---- epilogue through LDS (gemm_epilogue.h; the operand stages are dead after the last barrier) ----
-    gemm_epilogue_wave<EPI>(a, acc, smem + wid * EPI_REGION, m0 + wm * 64, n0 + wn * 128, lane);
+    if (EPI == EPI_RESID_LN_PRE || EPI == EPI_RESID_LN_POST)
+        gemm_epilogue_tile_ln<EPI == EPI_RESID_LN_POST>(a, acc, smem, m0, n0, tm, tn, wid, wm, wn, lane);
+    else
+        gemm_epilogue_wave<EPI>(a, acc, smem + wid * EPI_REGION, m0 + wm * 64, n0 + wn * 128, lane);
 }
 
 template <int EPI>
@@ -261,13 +264,14 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     bool& attr_set = attr_done[dev_ & 63];
+    constexpr int LDS = (EPI == EPI_RESID_LN_PRE || EPI == EPI_RESID_LN_POST) ? LN_LDS_TOTAL : LDS_TOTAL;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int grid = (a.M >> 8) * (a.N >> 8);
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS_TOTAL, s, a);
+    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS, s, a);
     return hipGetLastError();
 }
 
@@ -284,6 +288,12 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
         case EPI_BIAS_RESID_F32: return launch_t<EPI_BIAS_RESID_F32>(a, s);
         case EPI_BIAS_F32: return launch_t<EPI_BIAS_F32>(a, s);
         case EPI_PATCH_F32: return launch_t<EPI_PATCH_F32>(a, s);
+        case EPI_RESID_LN_PRE: return gemm256_ln_ok(a) && a.resid ? launch_t<EPI_RESID_LN_PRE>(a, s) : hipErrorInvalidValue;
+        case EPI_RESID_LN_POST: return gemm256_ln_ok(a) ? launch_t<EPI_RESID_LN_POST>(a, s) : hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;
+}
+
+bool gemm256_ln_ok(const GemmArgs& a) {
+    return gemm256_ok(a) && (a.N == 768 || a.N == 1024) && a.ln_g && a.ln_b && a.ln_out && a.ln_stats && a.ln_cnt && a.out;
 }

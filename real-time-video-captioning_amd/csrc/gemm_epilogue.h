@@ -8,6 +8,7 @@
 // segments: 16 B per lane, 128 B (bf16) or 256 B (fp32) per row.
 #pragma once
 #include "kernels.h"
+#include "ln_canon.h"
 
 constexpr int EPI_REGION = 64 * (64 * 4 + 16);   // per-wave staging (fp32 worst case): 17408 B
 
@@ -83,5 +84,143 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& a, const f32x
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      // reads done before the next half-block overwrites
+    }
+}
+
+// ---- residual + LayerNorm epilogue of a whole 256x256 tile (EPI_RESID_LN_*; gemm256.hip) ------------------------
+// LDS beyond the 8 staging regions: the tile's segment statistics and each wave's row (mean, rstd).
+constexpr int LN_STATS_OFF = 8 * EPI_REGION;                 // float2 [256 rows][4 segments]
+constexpr int LN_ROWS_OFF = LN_STATS_OFF + 256 * 4 * 8;      // float2 [8 waves][64 rows]
+constexpr int LN_LDS_TOTAL = LN_ROWS_OFF + 8 * 64 * 8;       // 151552 B
+
+__device__ __forceinline__ void ln_store_agent(float2* p, float2 v) {
+    __hip_atomic_store((unsigned long long*)p, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ln_load_agent(const float2* p) {
+    return __builtin_bit_cast(float2, __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// The wave's 128(n) x 64(m) block goes through LDS to the row-wise layout as in gemm_epilogue_wave (lane = 4 consecutive
+// n of row it*4 + (lane >> 4)), where 16 lanes hold one 64-column segment of a row: x = acc + bias [+ resid] stays in
+// registers (they replace the accumulators), the segment statistics go to LDS, then -- the tile's 4 segments per row
+// together -- to global memory with agent-scope stores; one arrival per tile on the row block's counter; x is written
+// (PRE) while the other tiles of the row block arrive; then every wave merges the NSEG segments of its 64 rows in the
+// canonical order and normalises its registers.  Tiles of a row block have consecutive logical ids (same or adjacent
+// dispatch), and a tile never waits for anything before it publishes, so the wait is bounded by the slowest sibling;
+// workgroups are dispatched in index order, so a waiting tile can only wait for a tile that is resident or that will
+// be dispatched as soon as any tile with all siblings resident retires: no deadlock; the spin is bounded + trap.
+template <bool POST>
+__device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f32x4 (&acc)[2][4][2][2], char* smem,
+                                                      const int m0, const int n0, const int tm, const int tn,
+                                                      const int wid, const int wm, const int wn, const int lane) {
+    const int frow = lane & 15, fq = lane >> 4;
+    constexpr int RS = 64 * 4 + 16;
+    char* ep = smem + wid * EPI_REGION;
+    float2* st_lds = (float2*)(smem + LN_STATS_OFF);
+    float2* row_lds = (float2*)(smem + LN_ROWS_OFF) + wid * 64;
+    const int rr = lane >> 4, rc = lane & 15;              // row-wise role: 16 lanes per row, 4 rows per instruction
+    const int mw = m0 + wm * 64, nw = n0 + wn * 128;
+    // the row block's barrier {count, generation}; the generation is read now (it cannot move before this tile arrives)
+    unsigned* bar = a.ln_cnt + 2 * tm;
+    unsigned my_gen = 0;
+    if (threadIdx.x == 0) my_gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f32x4 xr[2][16];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int nb = nw + x * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int nl = i * 16 + fq * 4;
+            f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.bias) bias4 = *(const f32x4*)(a.bias + nb + nl);
+#pragma unroll
+            for (int y = 0; y < 2; ++y)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int ml = y * 32 + j * 16 + frow;
+                    *(f32x4*)(ep + ml * RS + nl * 4) = acc[x][i][y][j] + bias4;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int ml = it * 4 + rr;
+            const int m = mw + ml, n = nb + rc * 4;
+            f32x4 v = *(const f32x4*)(ep + ml * RS + rc * 16);
+            if (a.resid) v += *(const f32x4*)(a.resid + (size_t)m * a.ldr + n);
+            xr[x][it] = v;
+            const float2 st = ln_seg_stats(v);
+            if (rc == 0) st_lds[(wm * 64 + ml) * 4 + wn * 2 + x] = st;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    {   // publish the tile's 256 x 4 segment statistics: thread -> (row, two segments)
+        const int t = threadIdx.x, row = t >> 1, sg = (t & 1) * 2;
+        float2* dst = a.ln_stats + (size_t)(m0 + row) * 16 + tn * 4 + sg;
+        ln_store_agent(dst, st_lds[row * 4 + sg]);
+        ln_store_agent(dst + 1, st_lds[row * 4 + sg + 1]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // written through before the arrival is announced
+    __syncthreads();
+    // arrival on the row block's barrier {count, generation}: the last of the N/256 tiles resets the count and bumps the
+    // generation (nothing else touches the pair until the next launch on the stream); the others wait for the bump
+    bool last = false;
+    if (threadIdx.x == 0) {
+        last = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(a.N >> 8) - 1u;
+        if (last) {
+            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(bar + 1, my_gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (!POST) {                                            // x itself (the residual stream) goes out while the siblings arrive
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int it = 0; it < 16; ++it)
+                *(f32x4*)((float*)a.out + (size_t)(mw + it * 4 + rr) * a.ldo + nw + x * 64 + rc * 4) = xr[x][it];
+    }
+    if (threadIdx.x == 0 && !last) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen) {
+            __builtin_amdgcn_s_sleep(12);                   // ~0.3 us between polls: 200 spinning tiles must not load the fabric
+            if (++spins > (1u << 22)) __builtin_trap();
+        }
+    }
+    __syncthreads();
+    {   // lane -> row lane of the wave's 64 rows: merge the row's segments (all tiles) in the canonical order
+        const float2* src = a.ln_stats + (size_t)(mw + lane) * 16;
+        float mean, rstd;
+        if (a.N == 768) {
+            float2 sg[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) sg[q] = ln_load_agent(src + q);
+            ln_merge<12>([&](int q) { return sg[q]; }, a.ln_eps, mean, rstd);
+        } else {
+            float2 sg[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sg[q] = ln_load_agent(src + q);
+            ln_merge<16>([&](int q) { return sg[q]; }, a.ln_eps, mean, rstd);
+        }
+        row_lds[lane] = float2{mean, rstd};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        const int n = nw + x * 64 + rc * 4;
+        const f32x4 g4 = *(const f32x4*)(a.ln_g + n), b4 = *(const f32x4*)(a.ln_b + n);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int ml = it * 4 + rr;
+            const float2 mr = row_lds[ml];
+            const f32x4 y = ln_apply(xr[x][it], mr.x, mr.y, g4, b4);
+            const size_t m = (size_t)(mw + ml);
+            if (POST) *(f32x4*)((float*)a.out + m * a.ldo + n) = y;
+            uint2 o;
+            o.x = pack_bf2(y[0], y[1]);
+            o.y = pack_bf2(y[2], y[3]);
+            *(uint2*)(a.ln_out + m * a.ld_ln + n) = o;
+        }
     }
 }

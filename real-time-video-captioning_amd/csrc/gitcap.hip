@@ -62,6 +62,8 @@ struct gitcap {
 
     // workspace (image rows)
     float *x = nullptr, *tmp = nullptr;
+    float2* ln_stats = nullptr;         // [Mi][16] LayerNorm segment statistics exchanged inside the fused GEMMs
+    unsigned* ln_cnt = nullptr;         // [Mi / 256][2] {arrivals, generation} per 256-row block (self-resetting barrier)
     bf16_t *hb = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr, *patches = nullptr, *kv_img = nullptr;
     // workspace (text rows)
     float *xs = nullptr, *slabs = nullptr, *part = nullptr, *amax_val = nullptr;
@@ -298,6 +300,37 @@ int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef
     return 0;
 }
 
+// GEMM (+ bias [+ residual]) followed by LayerNorm of its output rows.
+//   post = false (pre-LN ViT block):   x = A W^T + bias + resid -> xout (fp32, may alias resid);  ln_b = bf16 LN(x)
+//   post = true  (post-LN decoder):    x = A W^T + bias [+ resid] -> scratch; xout = fp32 LN(x) (may alias resid); ln_b = bf16 LN(x)
+// Large launches run both inside the 256x256 kernel (EPI_RESID_LN_*: the tiles of a row block exchange segment
+// statistics); small ones the 128x128 kernel + the row kernel.  Both give the same bits (ln_canon.h).
+// GITCAP_NO_GEMM_LN=1 (diagnosis / A-B only) keeps every LayerNorm a launch of its own.
+const bool g_fuse_ln = getenv("GITCAP_NO_GEMM_LN") == nullptr;
+
+int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const WRef& W, const float* bias, int M, int N,
+            int K, float* xout, const float* resid, const float* ln_g, const float* ln_b, float eps, int rows,
+            bf16_t* ln_out, float* scratch) {
+    hipError_t e;
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = xout; a.ldo = N; a.resid = resid; a.ldr = N;
+    a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = eps; a.ln_out = ln_out; a.ld_ln = N; a.ln_stats = h->ln_stats; a.ln_cnt = h->ln_cnt;
+    // ln_out may be the A operand itself (visual projection): a tile writes its rows only after every tile that reads
+    // them has finished its K loop (that is what the exchange waits for) -- as long as both views have the same row stride
+    const bool alias_ok = (const void*)A != (const void*)ln_out || lda == N;
+    if (g_fuse_ln && alias_ok && gemm256_ln_ok(a) && (M >> 8) * (N >> 8) >= g_small_tiles && (post || resid)) {
+        a.W = stage_weight(h, s, W, N, K, &e);
+        HIP_OK(h, e);
+        ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * h->prof_rows * N * K, 0.0);
+        HIP_OK(h, launch_gemm256(a, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s));
+        return 0;
+    }
+    int rc;
+    float* xo = post ? scratch : xout;
+    if ((rc = gemm(h, s, resid ? EPI_BIAS_RESID_F32 : EPI_BIAS_F32, A, lda, W, bias, M, N, K, xo, N, resid, N))) return rc;
+    return ln(h, s, xo, N, ln_g, ln_b, eps, rows, N, post ? xout : nullptr, N, ln_out, N);
+}
+
 int skinny(gitcap* h, hipStream_t s, int epi, const bf16_t* X, int ldx, const WRef& W, const float* bias, int M,
            int N, int K, void* out, int ldo, int T = 1, int row_stride = 1, int row_off = 0) {
     ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * M * N * K, (W.scale ? 1.0 : 2.0) * N * K);
@@ -327,8 +360,8 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
     int rc;
     h->prof_rows = rows;
     // 'linearLn' projection: Linear(Dv -> D) + LayerNorm
-    if ((rc = gemm(h, s, EPI_BIAS_F32, h->hb, Dv, h->vproj_w, h->vproj_b, Mp, D, Dv, h->tmp, D))) return rc;
-    if ((rc = ln(h, s, h->tmp, D, h->vproj_lnw, h->vproj_lnb, c.proj_ln_eps, rows, D, h->x, D, h->hb, D))) return rc;
+    if ((rc = gemm_ln(h, s, true, h->hb, Dv, h->vproj_w, h->vproj_b, Mp, D, Dv, h->x, nullptr, h->vproj_lnw, h->vproj_lnb,
+                      c.proj_ln_eps, rows, h->hb, h->tmp))) return rc;
     const size_t kv_layer = (size_t)h->Mi * 3 * D;
     const bool hid = h->want_hidden && h->cur_slot == 0;     // hidden-state export: synchronous path only
     auto keep = [&](int entry) -> hipError_t {
@@ -344,11 +377,11 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
                 ProfScope ps(h, GITCAP_PROF_ATTN_FULL, s, 4.0 * B * c.dec_heads * (double)S * S * 64, 0.0);
                 HIP_OK(h, launch_attn_full(kv, h->ctx, B, S, c.dec_heads, s));
             }
-            if ((rc = gemm(h, s, EPI_BIAS_RESID_F32, h->ctx, D, L.aow, L.aob, Mp, D, D, h->tmp, D, h->x, D))) return rc;
-            if ((rc = ln(h, s, h->tmp, D, L.ln1w, L.ln1b, c.dec_ln_eps, rows, D, h->x, D, h->hb, D))) return rc;
+            if ((rc = gemm_ln(h, s, true, h->ctx, D, L.aow, L.aob, Mp, D, D, h->x, h->x, L.ln1w, L.ln1b, c.dec_ln_eps, rows,
+                              h->hb, h->tmp))) return rc;
             if ((rc = gemm(h, s, EPI_BIAS_GELU_BF16, h->hb, D, L.fc1w, L.fc1b, Mp, c.dec_ffn, D, h->ffn, c.dec_ffn))) return rc;
-            if ((rc = gemm(h, s, EPI_BIAS_RESID_F32, h->ffn, c.dec_ffn, L.fc2w, L.fc2b, Mp, D, c.dec_ffn, h->tmp, D, h->x, D))) return rc;
-            if ((rc = ln(h, s, h->tmp, D, L.ln2w, L.ln2b, c.dec_ln_eps, rows, D, h->x, D, h->hb, D))) return rc;
+            if ((rc = gemm_ln(h, s, true, h->ffn, c.dec_ffn, L.fc2w, L.fc2b, Mp, D, c.dec_ffn, h->x, h->x, L.ln2w, L.ln2b,
+                              c.dec_ln_eps, rows, h->hb, h->tmp))) return rc;
             HIP_OK(h, keep(l + 1));
         } else {
             // last layer: image rows are only ever read as keys/values -> K,V projections only
@@ -492,6 +525,8 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     const size_t Mi = h->Mi, Mt = h->Mt;
     rc = rc ? rc : ws_alloc(h, &h->x, Mi * Dm);
     rc = rc ? rc : ws_alloc(h, &h->tmp, Mi * h->D);
+    rc = rc ? rc : ws_alloc(h, &h->ln_stats, Mi * 16);
+    rc = rc ? rc : ws_alloc(h, &h->ln_cnt, 2 * (Mi / 256 + 1));
     rc = rc ? rc : ws_alloc(h, &h->hb, Mi * Dm);
     rc = rc ? rc : ws_alloc(h, &h->qkv, Mi * 3 * h->Dv);
     rc = rc ? rc : ws_alloc(h, &h->ctx, Mi * Dm);
@@ -741,18 +776,26 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
     h->prof_rows = rows;
     if ((rc = ln(h, s, h->x, Dv, h->ln_pre_w, h->ln_pre_b, c.enc_ln_eps, rows, Dv, h->x, Dv, nullptr, 0))) return rc;
 
+    // pre-LN blocks: x += proj(attn(LN1 x)); x += fc2(qgelu(fc1(LN2 x))).  Each residual GEMM also produces the
+    // LayerNorm its consumer needs (LN2 of this block / LN1 of the next), so only the first LN1 is a launch of its own.
+    if ((rc = ln(h, s, h->x, Dv, h->enc[0].ln1w, h->enc[0].ln1b, c.enc_ln_eps, rows, Dv, nullptr, 0, h->hb, Dv))) return rc;
     for (int i = 0; i < c.enc_layers; ++i) {
         const EncLayer& L = h->enc[i];
-        if ((rc = ln(h, s, h->x, Dv, L.ln1w, L.ln1b, c.enc_ln_eps, rows, Dv, nullptr, 0, h->hb, Dv))) return rc;
         if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, Dv, L.qkvw, L.qkvb, Mp, 3 * Dv, Dv, h->qkv, 3 * Dv))) return rc;
         {
             ProfScope ps(h, GITCAP_PROF_ATTN_FULL, s, 4.0 * nf * c.enc_heads * (double)N * N * 64, 0.0);
             HIP_OK(h, launch_attn_full(h->qkv, h->ctx, nf, N, c.enc_heads, s));
         }
-        if ((rc = gemm(h, s, EPI_BIAS_RESID_F32, h->ctx, Dv, L.projw, L.projb, Mp, Dv, Dv, h->x, Dv, h->x, Dv))) return rc;
-        if ((rc = ln(h, s, h->x, Dv, L.ln2w, L.ln2b, c.enc_ln_eps, rows, Dv, nullptr, 0, h->hb, Dv))) return rc;
+        if ((rc = gemm_ln(h, s, false, h->ctx, Dv, L.projw, L.projb, Mp, Dv, Dv, h->x, h->x, L.ln2w, L.ln2b, c.enc_ln_eps, rows,
+                          h->hb, nullptr))) return rc;
         if ((rc = gemm(h, s, EPI_BIAS_QGELU_BF16, h->hb, Dv, L.fc1w, L.fc1b, Mp, c.enc_ffn, Dv, h->ffn, c.enc_ffn))) return rc;
-        if ((rc = gemm(h, s, EPI_BIAS_RESID_F32, h->ffn, c.enc_ffn, L.fc2w, L.fc2b, Mp, Dv, c.enc_ffn, h->x, Dv, h->x, Dv))) return rc;
+        if (i + 1 < c.enc_layers) {
+            const EncLayer& Nx = h->enc[i + 1];
+            if ((rc = gemm_ln(h, s, false, h->ffn, c.enc_ffn, L.fc2w, L.fc2b, Mp, Dv, c.enc_ffn, h->x, h->x, Nx.ln1w, Nx.ln1b,
+                              c.enc_ln_eps, rows, h->hb, nullptr))) return rc;
+        } else {
+            if ((rc = gemm(h, s, EPI_BIAS_RESID_F32, h->ffn, c.enc_ffn, L.fc2w, L.fc2b, Mp, Dv, c.enc_ffn, h->x, Dv, h->x, Dv))) return rc;
+        }
     }
     // ln_post (+ per-frame temporal embedding, model.py:380); frames of a clip are already
     // adjacent rows, so the concat along tokens (model.py:382) is the identity on this layout
@@ -978,6 +1021,41 @@ int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float
     if (epi < 0 || epi > EPI_BIAS_F32) return GITCAP_ERR_ARG;
     if (tile != 128 && tile != 256) return GITCAP_ERR_ARG;
     hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
+}
+
+// GEMM + bias [+ resid] + LayerNorm: fused = 1 the EPI_RESID_LN_* epilogue of the 256x256 kernel, 0 = GEMM (tile) then the
+// row kernel; post as in gemm_ln (gitcap.hip).  out_f32: post ? LN(x) : x.  Scratch for the exchange is allocated here.
+int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const float* resid, const float* gamma,
+                       const float* beta, float eps, float* out_f32, void* out_bf16, int M, int N, int K, int post,
+                       int fused, int tile, void* stream) {
+    static float2* stats = nullptr; static unsigned* cnt = nullptr; static int cap = 0;
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.lda = K; a.W = (const bf16_t*)W; a.bias = bias; a.M = M; a.N = N; a.K = K;
+    a.out = out_f32; a.ldo = N; a.resid = resid; a.ldr = N;
+    if (!fused) {
+        if (tile != 128 && tile != 256) return GITCAP_ERR_ARG;
+        float* xo = out_f32;
+        float* tmp = nullptr;
+        if (post) { if (hipMalloc(&tmp, (size_t)M * N * 4) != hipSuccess) return GITCAP_ERR_NOMEM; xo = tmp; a.out = tmp; }
+        hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, resid ? EPI_BIAS_RESID_F32 : EPI_BIAS_F32, s);
+        if (e == hipSuccess) {
+            LnArgs l{xo, N, gamma, beta, eps, M, N, post ? out_f32 : nullptr, N, (bf16_t*)out_bf16, N, nullptr, 1, 1};
+            e = launch_layernorm(l, s);
+        }
+        if (tmp) { (void)hipStreamSynchronize(s); (void)hipFree(tmp); }
+        return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
+    }
+    if (M / 256 + 1 > cap) {
+        if (stats) { (void)hipFree(stats); (void)hipFree(cnt); }
+        cap = M / 256 + 1;
+        if (hipMalloc(&stats, (size_t)cap * 256 * 16 * sizeof(float2)) != hipSuccess || hipMalloc(&cnt, (size_t)cap * 8) != hipSuccess) return GITCAP_ERR_NOMEM;
+        if (hipMemset(cnt, 0, (size_t)cap * 8) != hipSuccess) return GITCAP_ERR_HIP;
+    }
+    a.ln_g = gamma; a.ln_b = beta; a.ln_eps = eps; a.ln_out = (bf16_t*)out_bf16; a.ld_ln = N; a.ln_stats = stats; a.ln_cnt = cnt;
+    if (!gemm256_ln_ok(a) || (!post && !resid)) return GITCAP_ERR_ARG;
+    const hipError_t e = launch_gemm256(a, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s);
     return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
 }
 

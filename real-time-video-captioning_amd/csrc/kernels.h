@@ -9,7 +9,11 @@ enum GemmEpi {
     EPI_BIAS_GELU_BF16 = 2,   // out bf16 = erf_gelu(acc + bias)        (BERT intermediate)
     EPI_BIAS_RESID_F32 = 3,   // out f32  = acc + bias + resid          (out may alias resid)
     EPI_BIAS_F32 = 4,         // out f32  = acc + bias
-    EPI_PATCH_F32 = 5         // out f32 row (frame*N + 1 + patch) = acc + pos[1+patch]
+    EPI_PATCH_F32 = 5,        // out f32 row (frame*N + 1 + patch) = acc + pos[1+patch]
+    // 256x256 kernel only, N = 768 or 1024: the tiles of one row block exchange LayerNorm statistics (ln_canon.h)
+    // and each normalises its own columns -> the LayerNorm launch behind the GEMM and its re-read disappear.
+    EPI_RESID_LN_PRE = 6,     // x = acc + bias + resid: out f32 = x, ln_out bf16 = LayerNorm(x)        (pre-LN ViT block)
+    EPI_RESID_LN_POST = 7     // x = acc + bias [+ resid]: out f32 = LayerNorm(x), ln_out bf16 = the same (post-LN decoder)
 };
 struct GemmArgs {
     const bf16_t* A; int lda;     // activations [M][lda], M multiple of 128 (padded rows are junk)
@@ -20,10 +24,16 @@ struct GemmArgs {
     const float* resid; int ldr;
     const float* pos;             // EPI_PATCH: [tokens_per_frame][N]
     int tokens_per_frame, patches_per_frame, valid_rows;
+    // EPI_RESID_LN_*: LayerNorm of the output rows
+    const float *ln_g, *ln_b; float ln_eps;
+    bf16_t* ln_out; int ld_ln;    // bf16 LayerNorm output
+    float2* ln_stats;             // [M][16] per-segment (mean, M2) exchanged between the tiles of a row block
+    unsigned* ln_cnt;             // [M / 256][2] per row block {arrivals, generation}: zero before the first launch, self-resetting
 };
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);      // 128x128 tile (any M%128, N%128)
 bool gemm256_ok(const GemmArgs& a);
 hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);   // 256x256 tile, 8-wave ping-pong
+bool gemm256_ln_ok(const GemmArgs& a);                                   // shape the EPI_RESID_LN_* epilogues accept
 
 // ---- skinny GEMMs (text rows; M = a few 16-row tiles): weight streaming, one wave per tile ----
 enum SkinnyEpi { SK_BIAS_BF16 = 0, SK_BIAS_GELU_BF16 = 1, SK_BIAS_RELU_BF16 = 2, SK_BIAS_F32 = 3 };

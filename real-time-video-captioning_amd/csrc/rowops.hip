@@ -1,41 +1,59 @@
 // HBM-bound row kernels: LayerNorm (one wave per row, 16-byte vector loads), patch gather
 // (im2col of NCHW fp32 frames, coalesced 16-B reads along W), text embedding, argmax.
 #include "kernels.h"
+#include "ln_canon.h"
 
 namespace {
 
 // ---- LayerNorm -------------------------------------------------------------------------------
-// One wave per row; lane holds NV float4 at columns 256*i + 4*lane (1 KiB contiguous per
-// wave-instruction).  Two-pass (mean, then centred variance) in registers, fp32 throughout.
-template <int NV>
+// One wave per row; lane holds NV float4 at columns 256*i + 4*lane (1 KiB contiguous per wave-instruction), fp32
+// throughout.  CANON (D a multiple of 64): the segmented statistics of ln_canon.h -- 16 lanes x 4 columns are one
+// 64-column segment, so (i, lane >> 4) names segment 4 i + (lane >> 4) -- bit for bit what the GEMM epilogue that
+// normalises its own rows computes.  Otherwise: two-pass (mean, then centred variance) over the wave.
+template <int NV, bool CANON>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
     const float* xr = a.x + (size_t)row * a.ldx;
     f32x4 v[NV];
-    float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
-        if (c < a.D) {
-            v[i] = *(const f32x4*)(xr + c);
-            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-        } else {
-            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        v[i] = c < a.D ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float mean = wave_sum(s) / (float)a.D;
-    float q = 0.f;
+    float mean, rstd;
+    if (CANON) {
+        float2 st[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = i * 256 + lane * 4;
-        if (c < a.D) {
+        for (int i = 0; i < NV; ++i) st[i] = ln_seg_stats(v[i]);        // segment 4 i + (lane >> 4), in all of its 16 lanes
+        auto seg = [&](int sidx) {                                      // segment sidx -> every lane (compile-time index)
+            const int src = (sidx & 3) * 16;
+            return float2{__shfl(st[sidx >> 2].x, src), __shfl(st[sidx >> 2].y, src)};
+        };
+        if (a.D == 768) ln_merge<12>(seg, a.eps, mean, rstd);
+        else if (a.D == 1024) ln_merge<16>(seg, a.eps, mean, rstd);
+        else if (a.D == 128) ln_merge<2>(seg, a.eps, mean, rstd);
+        else if (a.D == 64) ln_merge<1>(seg, a.eps, mean, rstd);
+        else if (a.D == 256) ln_merge<4>(seg, a.eps, mean, rstd);
+        else if (a.D == 512) ln_merge<8>(seg, a.eps, mean, rstd);
+        else { mean = 0.f; rstd = 0.f; }                                // launcher never sends other widths here
+    } else {
+        float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        for (int i = 0; i < NV; ++i) s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        mean = wave_sum(s) / (float)a.D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 256 + lane * 4;
+            if (c < a.D) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            }
         }
+        rstd = rsqrtf(wave_sum(q) / (float)a.D + a.eps);
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)a.D + a.eps);
     const float* addv = a.add_vec ? a.add_vec + (size_t)((row / a.add_div) % a.add_mod) * a.D : nullptr;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -44,8 +62,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
             const f32x4 g = *(const f32x4*)(a.gamma + c);
             const f32x4 b = *(const f32x4*)(a.beta + c);
             f32x4 y;
+            if (CANON) {
+                y = ln_apply(v[i], mean, rstd, g, b);
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+                for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            }
             if (addv) y += *(const f32x4*)(addv + c);
             if (a.out_f32) *(f32x4*)(a.out_f32 + (size_t)row * a.ld_f32 + c) = y;
             if (a.out_bf16) {
@@ -508,11 +530,16 @@ hipError_t launch_layernorm(const LnArgs& a, hipStream_t s) {
     if (a.rows <= 0 || a.D % 4 || a.D > 1024) return hipErrorInvalidValue;
     const int grid = (a.rows + 3) / 4;
     const int nv = (a.D + 255) / 256;
-    switch (nv) {
-        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, dim3(grid), dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, dim3(grid), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, s, a); break;
+    const bool canon = a.D == 64 || a.D == 128 || a.D == 256 || a.D == 512 || a.D == 768 || a.D == 1024;
+    switch (nv * 2 + (canon ? 1 : 0)) {
+        case 2: hipLaunchKernelGGL((layernorm_kernel<1, false>), dim3(grid), dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL((layernorm_kernel<1, true>), dim3(grid), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((layernorm_kernel<2, false>), dim3(grid), dim3(256), 0, s, a); break;
+        case 5: hipLaunchKernelGGL((layernorm_kernel<2, true>), dim3(grid), dim3(256), 0, s, a); break;
+        case 6: hipLaunchKernelGGL((layernorm_kernel<3, false>), dim3(grid), dim3(256), 0, s, a); break;
+        case 7: hipLaunchKernelGGL((layernorm_kernel<3, true>), dim3(grid), dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((layernorm_kernel<4, false>), dim3(grid), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((layernorm_kernel<4, true>), dim3(grid), dim3(256), 0, s, a); break;
     }
     return hipGetLastError();
 }

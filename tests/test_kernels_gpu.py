@@ -83,6 +83,36 @@ def test_gemm_tile_variants_are_bitwise_equal(lib):
             assert torch.equal(outs[0], o)
 
 
+@pytest.mark.parametrize("M,N,K,post,with_resid", [(1024, 768, 768, 0, True), (1024, 768, 768, 1, True), (768, 768, 3072, 1, False),
+                                                   (512, 1024, 256, 0, True), (19200, 768, 768, 0, True), (19200, 768, 3072, 1, True)])
+def test_gemm_layernorm_epilogue_equals_gemm_then_layernorm(lib, M, N, K, post, with_resid):
+    """The residual GEMM that normalises its own rows (tiles of a 256-row block exchange segment statistics) must give the
+    bits of the GEMM (either tile kernel) followed by the row kernel -- which of them runs depends on the batch size --
+    and both must be LayerNorm(A W^T + bias + resid) to fp32 accuracy.  19200 rows = the bench shape (225 tiles, one round)."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g)
+    resid = torch.randn(M, N, device="cuda", generator=g) * 2 + 0.5 if with_resid else None
+    gamma, beta = torch.randn(N, device="cuda", generator=g), torch.randn(N, device="cuda", generator=g)
+    outs = []
+    for fused, tile in ((1, 256), (0, 256), (0, 128)):
+        of = torch.full((M, N), float("nan"), device="cuda")
+        ob = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        for _ in range(2):          # twice: the exchange barrier must be reusable
+            assert lib.gitcap_dbg_gemm_ln(_p(A), _p(W), _p(bias), _p(resid), _p(gamma), _p(beta), ctypes.c_float(1e-5), _p(of), _p(ob),
+                                          M, N, K, post, fused, tile, _stream()) == 0
+        torch.cuda.synchronize()
+        outs.append((of, ob))
+    for of, ob in outs[1:]:
+        assert torch.equal(outs[0][0], of) and torch.equal(outs[0][1], ob)
+    x = A.float() @ W.float().t() + bias + (resid if with_resid else 0)
+    ln = torch.nn.functional.layer_norm(x, (N,), gamma, beta, 1e-5)
+    of, ob = outs[0]
+    assert torch.allclose(of, ln if post else x, rtol=1e-4, atol=2e-4 * K ** 0.5)
+    assert (ob.float() - ln).abs().max().item() < 0.05
+
+
 @pytest.mark.parametrize("G,S,H", [(3, 197, 12), (2, 1182, 12), (4, 17, 2), (1, 64, 1), (2, 65, 3), (1, 257, 16)])
 def test_attn_full_vs_reference(lib, G, S, H):
     W = H * 64

@@ -395,6 +395,80 @@ def test_teacher_forward_dicts(captioner_cls):
     assert r2[0]["cap"] is None and r2[0]["output"].shape[0] == 1 and r2[0]["output"].shape[2] == cfg.vocab_size
 
 
+def _beam_search_matches_margin_gated(dev_out, host_out, oracle_step, oracle_search, cfg, B, beams, max_steps, length_penalty):
+    """Beam search against the oracle when a device logit may differ from the oracle's by LOGIT_TOL_EMUL: the two searches
+    may legitimately part where candidates tie within that noise, and not otherwise.
+      1. the device-resident search == the host operator over the device's step logits (bitwise);
+      2. the oracle's search loop (model.py:479-678) REPLAYED over the device's saved step logits reproduces the device's
+         result exactly (the bookkeeping is the same) and yields the device's beams at every step;
+      3. oracle beams vs device beams step by step: identical sets until the first step whose pruning differs; at that
+         step every candidate one side kept and the other dropped lies within 2 x the measured score noise of the
+         oracle's cut (and that noise is below NEAR_TIE);
+      4. no divergence -> same hypothesis, logprobs within 0.05."""
+    import torch.nn.functional as Fn
+    assert torch.equal(dev_out["predictions"], host_out["predictions"])
+    assert torch.allclose(dev_out["logprobs"].cpu(), host_out["logprobs"].cpu(), atol=1e-5)
+    dev_logits = [torch.as_tensor(l).float().cpu() for l in host_out["logits_dict"]]
+    start = torch.full((B, 1), cfg.cls_token_id)
+    dev_trace, ora_trace = [], []
+
+    def replay(t):
+        dev_trace.append(t.clone())
+        return dev_logits[len(dev_trace) - 1]
+
+    def ora(t):
+        ora_trace.append(t.clone())
+        return oracle_step(t)
+    got = oracle_search(start, replay, eos_index=cfg.sep_token_id, max_steps=max_steps, beam_size=beams, length_penalty=length_penalty)
+    assert torch.equal(got[0], dev_out["predictions"].cpu()) and torch.allclose(got[1], dev_out["logprobs"].cpu(), atol=1e-4)
+    want = oracle_search(start, ora, eos_index=cfg.sep_token_id, max_steps=max_steps, beam_size=beams, length_penalty=length_penalty)
+    ora_logits = want[2]
+    for b in range(B):
+        rows = slice(b * beams, (b + 1) * beams)
+        diverged = False
+        for k in range(min(len(dev_trace), len(ora_trace))):
+            d, o = dev_trace[k][rows], ora_trace[k][rows]
+            if sorted(map(tuple, d.tolist())) == sorted(map(tuple, o.tolist())):
+                continue
+            # the pruning of step k-1 differed: score every (beam, token) candidate of that step on both sides
+            j = k - 1
+            dj, oj = dev_trace[j][rows].tolist(), ora_trace[j][rows].tolist()
+            perm = [dj.index(r) for r in oj]                      # oracle row -> device row with the same prefix
+            lo = Fn.log_softmax(ora_logits[j][rows].float(), -1)
+            ld = Fn.log_softmax(dev_logits[j][rows][perm], -1)
+            # beam scores are sums of earlier candidates' log-probs: rebuild them per prefix from the traces
+            def prefix_scores(trace, logits):
+                sc = torch.zeros(beams)
+                for r, pre in enumerate(trace[j][rows].tolist()):
+                    tot = 0.0
+                    for q in range(1, len(pre)):
+                        prow = [tuple(x) for x in trace[q - 1][rows].tolist()].index(tuple(pre[:q]))
+                        tot += float(Fn.log_softmax(logits[q - 1][rows][prow].float(), -1)[pre[q]])
+                    sc[r] = tot
+                return sc
+            so = prefix_scores(ora_trace, ora_logits)
+            sd = prefix_scores(dev_trace, dev_logits)[perm]
+            if j == 0:
+                so[1:] = -1e9; sd[1:] = -1e9                       # model.py:509: all beams start as copies of one
+            co, cd = (lo + so[:, None]).flatten(), (ld + sd[:, None]).flatten()
+            top = torch.unique(torch.cat([co.topk(3 * beams).indices, cd.topk(3 * beams).indices]))
+            noise = float((co[top] - cd[top]).abs().max())
+            assert noise < NEAR_TIE, (b, j, noise)
+            V = lo.shape[-1]
+            kept_o = {tuple(r) for r in o.tolist()}
+            kept_d = {tuple(r) for r in d.tolist()}
+            cut = min(float(co[oj.index(list(pre[:-1])) * V + pre[-1]]) for pre in kept_o)
+            for pre in kept_o ^ kept_d:
+                gap = abs(float(co[oj.index(list(pre[:-1])) * V + pre[-1]]) - cut)
+                assert gap <= 2 * noise + 1e-6, (b, j, pre, gap, noise)
+            diverged = True
+            break
+        if not diverged:
+            assert torch.equal(dev_out["predictions"][b].cpu(), want[0][b])
+            assert abs(float(dev_out["logprobs"][b].cpu() - want[1][b])) < 0.05
+
+
+
 def test_config4_real_shape_fp8_beam(captioner_cls):
     """BASELINE configs[4] at its real shape: GIT-large (ViT-L/14, parameter.yaml:1-3), 10-frame clip, e4m3 weight
     storage, beam 4, 15 steps (model.py:702-708).  Teacher-forced logits against the bf16-emulating oracle on the same
@@ -421,16 +495,13 @@ def test_config4_real_shape_fp8_beam(captioner_cls):
         l_e = emul.decoder_text(ikv, ids)
     assert (lg - l_e).abs().max() < LOGIT_TOL_EMUL * 1.5, float((lg - l_e).abs().max())
     out = m.infer(fr, beam_size=4, max_steps=15, length_penalty=0.6, on_device=True)
+    host = m.infer(fr, beam_size=4, max_steps=15, length_penalty=0.6, on_device=False, save_logits=True)
+    assert out["predictions"].shape == (1, 15)
 
     def step(t):
         with torch.no_grad():
             return emul.decoder_text(ikv, t, torch.zeros(t.shape[0], dtype=torch.long))[:, -1]
-    want = oracle_beam_search(torch.full((1, 1), cfg.cls_token_id), step, eos_index=cfg.sep_token_id, max_steps=15,
-                              beam_size=4, length_penalty=0.6)
-    assert out["predictions"].shape == (1, 15)
-    assert torch.allclose(out["logprobs"].cpu(), want[1], atol=0.05), (out["logprobs"], want[1])
-    if not torch.equal(out["predictions"].cpu(), want[0]):           # another hypothesis only inside a near-tie
-        assert float((out["logprobs"].cpu() - want[1]).abs().max()) < 0.02
+    _beam_search_matches_margin_gated(out, host, step, oracle_beam_search, cfg, 1, 4, 15, 0.6)
 
 
 def test_device_beam_search_base_size(captioner_cls):
@@ -442,9 +513,7 @@ def test_device_beam_search_base_size(captioner_cls):
     fr = make_frames(2, 2, cfg.image_size, 52)
     m = captioner_cls(cfg, w, max_batch=2, max_frames=2, max_text_len=12, max_beams=4)
     dev = m.infer(fr, beam_size=4, max_steps=10, length_penalty=0.6, on_device=True)
-    host = m.infer(fr, beam_size=4, max_steps=10, length_penalty=0.6, on_device=False)
-    assert torch.equal(dev["predictions"], host["predictions"])
-    assert torch.allclose(dev["logprobs"].cpu(), host["logprobs"].cpu(), atol=1e-5)
+    host = m.infer(fr, beam_size=4, max_steps=10, length_penalty=0.6, on_device=False, save_logits=True)
     emul = GitOracle(cfg, w, emulate_bf16=True)
     with torch.no_grad():
         _, mem = emul.forward_image_enc(fr)
@@ -453,12 +522,7 @@ def test_device_beam_search_base_size(captioner_cls):
     def step(t):
         with torch.no_grad():
             return emul.decoder_text(ikv, t, torch.arange(2).repeat_interleave(4))[:, -1]
-    want = oracle_beam_search(torch.full((2, 1), cfg.cls_token_id), step, eos_index=cfg.sep_token_id, max_steps=10,
-                              beam_size=4, length_penalty=0.6)
-    assert torch.allclose(dev["logprobs"].cpu(), want[1], atol=0.05), (dev["logprobs"], want[1])
-    for b in range(2):
-        if not torch.equal(dev["predictions"][b].cpu(), want[0][b]):
-            assert abs(float(dev["logprobs"][b].cpu() - want[1][b])) < 0.02
+    _beam_search_matches_margin_gated(dev, host, step, oracle_beam_search, cfg, 2, 4, 10, 0.6)
 
 
 def test_forward_output_logits_hidden_states(captioner_cls, golden_dir):
