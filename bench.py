@@ -270,7 +270,10 @@ def main():
                     "traffic_source": traffic_src, "traffic_source_sha": traffic_sha, "library_source_sha": library_source_sha(),
                     "traffic_stale": (traffic_sha != library_source_sha()) if traffic is not None else None,
                     "launches_per_step": gm["launches"] // nprof, "avg_launch_ms": round(avg_ms, 4),
-                    "algorithmic_gflop_per_launch": round(gm["flops"] / max(1, gm["launches"]) / 1e9, 2)}
+                    "algorithmic_gflop_per_launch": round(gm["flops"] / max(1, gm["launches"]) / 1e9, 2),
+                    # the residual GEMMs normalise their own output rows (EPI_RESID_LN_*): their brackets contain what used
+                    # to be separate launches of the layernorm class (37 per step before; what is left is counted here)
+                    "layernorm_launches_per_step": prof["rowops"]["launches"] // nprof}
         def rate(cls, key, scale):
             v = prof[cls]
             return round(v[key] / (v["ms"] * 1e-3) / scale, 1) if v["ms"] > 0 and v[key] > 0 else None

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     // for tile t+2) in flight and retires everything of tile t+1, which is first read one barrier
     // later, in C3(t) (W-lo rows of tile t+1) and L0(t+1).
     const int nt = a.K >> 6;
+    LN_STAMP(0);
 #pragma unroll
     for (int w = 0; w < 4; ++w) dma_half(smem, w, 0);
     if (nt > 1) {
@@ -250,12 +251,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
         BARRIER();
     }
     if (grp == 0) BARRIER();                       // matches group 1's extra leading barrier
+    LN_STAMP(1);
 
     // ---- epilogue through LDS (gemm_epilogue.h; the operand stages are dead after the last barrier) ----
     if (EPI == EPI_RESID_LN_PRE || EPI == EPI_RESID_LN_POST)
         gemm_epilogue_tile_ln<EPI == EPI_RESID_LN_POST>(a, acc, smem, m0, n0, tm, tn, wid, wm, wn, lane);
     else
         gemm_epilogue_wave<EPI>(a, acc, smem + wid * EPI_REGION, m0 + wm * 64, n0 + wn * 128, lane);
+#ifdef LN_STAMPS
+    if (EPI != EPI_RESID_LN_PRE && EPI != EPI_RESID_LN_POST) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); LN_STAMP(7); }
+#endif
 }
 
 template <int EPI>

@@ -12,6 +12,14 @@
 
 constexpr int EPI_REGION = 64 * (64 * 4 + 16);   // per-wave staging (fp32 worst case): 17408 B
 
+// phase stamps: only in the diagnostic build of tools/probe/gemmln_probe.hip (the product kernels have none)
+#ifdef LN_STAMPS
+__device__ unsigned long long* g_ln_stamps;
+#define LN_STAMP(i) do { if (threadIdx.x == 0 && g_ln_stamps) g_ln_stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define LN_STAMP(i) do {} while (0)
+#endif
+
 // ep: this wave's EPI_REGION bytes of LDS; mw / nw: first m / n of the wave's block
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& a, const f32x4 (&acc)[2][4][2][2], char* ep,
@@ -93,19 +101,14 @@ constexpr int LN_STATS_OFF = 8 * EPI_REGION;                 // float2 [256 rows
 constexpr int LN_ROWS_OFF = LN_STATS_OFF + 256 * 4 * 8;      // float2 [8 waves][64 rows]
 constexpr int LN_LDS_TOTAL = LN_ROWS_OFF + 8 * 64 * 8;       // 151552 B
 
-__device__ __forceinline__ void ln_store_agent(float2* p, float2 v) {
-    __hip_atomic_store((unsigned long long*)p, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float2 ln_load_agent(const float2* p) {
-    return __builtin_bit_cast(float2, __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 // The wave's 128(n) x 64(m) block goes through LDS to the row-wise layout as in gemm_epilogue_wave (lane = 4 consecutive
-// n of row it*4 + (lane >> 4)), where 16 lanes hold one 64-column segment of a row: x = acc + bias [+ resid] stays in
-// registers (they replace the accumulators), the segment statistics go to LDS, then -- the tile's 4 segments per row
-// together -- to global memory with agent-scope stores; one arrival per tile on the row block's counter; x is written
-// (PRE) while the other tiles of the row block arrive; then every wave merges the NSEG segments of its 64 rows in the
-// canonical order and normalises its registers.  Tiles of a row block have consecutive logical ids (same or adjacent
+// n of row it*4 + (lane >> 4)), where 16 lanes hold one 64-column segment of a row: x = acc + bias [+ resid] is written
+// (PRE) and stays in registers (they replace the accumulators), the segment statistics go to LDS, then -- the tile's 4
+// segments per row together -- to global memory with 16-byte agent-scope stores; one arrival per tile on the row block's
+// barrier; then every wave fetches the 128 B of statistics of each of its 64 rows (coalesced), merges the NSEG segments
+// in the canonical order and normalises its registers.  Tiles of a row block have consecutive logical ids (same or adjacent
 // dispatch), and a tile never waits for anything before it publishes, so the wait is bounded by the slowest sibling;
 // workgroups are dispatched in index order, so a waiting tile can only wait for a tile that is resident or that will
 // be dispatched as soon as any tile with all siblings resident retires: no deadlock; the spin is bounded + trap.
@@ -148,21 +151,25 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
             const int m = mw + ml, n = nb + rc * 4;
             f32x4 v = *(const f32x4*)(ep + ml * RS + rc * 16);
             if (a.resid) v += *(const f32x4*)(a.resid + (size_t)m * a.ldr + n);
+            if (!POST) *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;      // x itself: the residual stream
             xr[x][it] = v;
             const float2 st = ln_seg_stats(v);
             if (rc == 0) st_lds[(wm * 64 + ml) * 4 + wn * 2 + x] = st;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    LN_STAMP(2);
     __syncthreads();
-    {   // publish the tile's 256 x 4 segment statistics: thread -> (row, two segments)
+    // [M][16] float2 through a buffer resource: 16-byte agent-scope (sc1, aux = 16) stores and loads
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)a.ln_stats, 0, a.M * 128, 0x00020000);
+    {   // publish the tile's 256 x 4 segment statistics: thread -> (row, two segments) = one 16-byte store
         const int t = threadIdx.x, row = t >> 1, sg = (t & 1) * 2;
-        float2* dst = a.ln_stats + (size_t)(m0 + row) * 16 + tn * 4 + sg;
-        ln_store_agent(dst, st_lds[row * 4 + sg]);
-        ln_store_agent(dst + 1, st_lds[row * 4 + sg + 1]);
+        const u32x4 v = *(const u32x4*)(st_lds + row * 4 + sg);
+        __builtin_amdgcn_raw_buffer_store_b128(v, srs, ((m0 + row) * 16 + tn * 4 + sg) * 8, 0, 16);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // written through before the arrival is announced
     __syncthreads();
+    LN_STAMP(3);
     // arrival on the row block's barrier {count, generation}: the last of the N/256 tiles resets the count and bumps the
     // generation (nothing else touches the pair until the next launch on the stream); the others wait for the bump
     bool last = false;
@@ -173,13 +180,7 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
             __hip_atomic_store(bar + 1, my_gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    if (!POST) {                                            // x itself (the residual stream) goes out while the siblings arrive
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int it = 0; it < 16; ++it)
-                *(f32x4*)((float*)a.out + (size_t)(mw + it * 4 + rr) * a.ldo + nw + x * 64 + rc * 4) = xr[x][it];
-    }
+    LN_STAMP(4);
     if (threadIdx.x == 0 && !last) {
         unsigned spins = 0;
         while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen) {
@@ -188,24 +189,26 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
         }
     }
     __syncthreads();
-    {   // lane -> row lane of the wave's 64 rows: merge the row's segments (all tiles) in the canonical order
-        const float2* src = a.ln_stats + (size_t)(mw + lane) * 16;
-        float mean, rstd;
-        if (a.N == 768) {
-            float2 sg[12];
+    LN_STAMP(5);
+    {   // the wave's 64 rows x 128 B of statistics: 8 coalesced 16-byte loads per lane into the wave's staging region,
+        // then lane -> row lane: merge the row's segments (all tiles) in the canonical order
 #pragma unroll
-            for (int q = 0; q < 12; ++q) sg[q] = ln_load_agent(src + q);
-            ln_merge<12>([&](int q) { return sg[q]; }, a.ln_eps, mean, rstd);
-        } else {
-            float2 sg[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) sg[q] = ln_load_agent(src + q);
-            ln_merge<16>([&](int q) { return sg[q]; }, a.ln_eps, mean, rstd);
+        for (int i = 0; i < 8; ++i) {
+            const int row = i * 8 + (lane >> 3), ch = lane & 7;
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srs, ((mw + row) * 16 + ch * 2) * 8, 0, 16);
+            *(u32x4*)(ep + row * 144 + ch * 16) = v;               // 144-byte row pitch: conflict-free 16-byte reads below
         }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const float2* src = (const float2*)(ep + lane * 144);
+        float mean, rstd;
+        if (a.N == 768) ln_merge<12>([&](int q) { return src[q]; }, a.ln_eps, mean, rstd);
+        else ln_merge<16>([&](int q) { return src[q]; }, a.ln_eps, mean, rstd);
         row_lds[lane] = float2{mean, rstd};
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    LN_STAMP(6);
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
         const int n = nw + x * 64 + rc * 4;
@@ -223,4 +226,8 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
             *(uint2*)(a.ln_out + m * a.ld_ln + n) = o;
         }
     }
+#ifdef LN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LN_STAMP(7);
+#endif
 }
