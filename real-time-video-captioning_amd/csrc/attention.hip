@@ -16,6 +16,7 @@
 //
 // (The attention of the TEXT rows -- decode steps and teacher-forced prefixes -- is in txtblock.hip.)
 #include "kernels.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int i = 0; i < NST - 1; ++i)
         if (i < ntiles) stage(i, i * 64);
-    for (int t = 0; t < ntiles; ++t) {
+    // entering tile t: its DMA has landed, every wave is past tile t-1, the next prefetch is issued
+    auto enter = [&](const int t) {
         const int ahead = min(NST - 2, ntiles - 1 - t);
         if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -129,19 +131,24 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
         asm volatile("" ::: "memory");
         if (t + NST - 1 < ntiles) stage((t + NST - 1) % NST, (t + NST - 1) * 64);
         if (t < 6) ATTN_STAMP(1 + 2 * t);          // barrier passed: tile t is in LDS
-        if (!wave_active) continue;
+    };
+    // One 64-key tile for this wave's 32 queries; NKT = number of 32-key halves computed.  The ragged last tile
+    // (S = 197: 5 of 64 keys, S = 1182: 30 of 64) with no valid key in its second half runs the NKT = 1 form: no
+    // K.Q^T MFMAs, exponentials or V^T.P^T steps for that half.  The skipped terms are exact zeros, so the result is
+    // bit for bit the masked full tile's.  The choice is wave-uniform.
+    auto tile = [&](auto nkt_c, const int t) {
+        constexpr int NKT = decltype(nkt_c)::value;
         const char* sb = lds + (t % NST) * 16384;
         const int key0 = t * 64;
-
         // ---- S^T = K . Q^T : all 8 K fragments are requested before the first MFMA -----------------
-        bf16x8 kf[2][4];
+        bf16x8 kf[NKT][4];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *(const bf16x8*)(sb + kt * 4096 + koff[ks]);
-        f32x16 s_acc[2];
+        f32x16 s_acc[NKT];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s_acc[kt][r] = 0.f;
 #pragma unroll
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
         }
         // ---- V^T fragments of the first 32 keys: requested now, consumed after the softmax; the second 32 keys'
         //      fragments are requested when the first half's MFMAs have been issued (16 fewer live registers) -----
-        bf16x4 vlo[2][2][2], vhi[2][2][2];
+        bf16x4 vlo[NKT][2][2], vhi[NKT][2][2];
         auto load_v = [&](int kt) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
         // ---- mask the ragged last tile (wave-uniform branch) ---------------------------------
         if (key0 + 64 > S) {
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = key0 + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * h2;
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
         // ---- online softmax (lane = query; its 32 keys + the other half-wave's 32) ------------
         float mt = s_acc[0][0];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s_acc[kt][r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32));
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
         const float mb = m_new * kScaleLog2e;
         float psum = 0.f;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = fast_exp2(s_acc[kt][r] * kScaleLog2e - mb);
@@ -202,8 +209,8 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
 
         // ---- O^T += V^T . P^T -----------------------------------------------------------------
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            if (kt == 0) load_v(1);
+        for (int kt = 0; kt < NKT; ++kt) {
+            if (kt == 0 && NKT == 2) load_v(1);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 // 8 probabilities -> one bf16x8 B fragment (4 x v_cvt_pk_bf16_f32)
@@ -219,7 +226,18 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
                 }
             }
         }
+    };
+    // full-form tiles; a last tile whose second half has no valid key runs the half form, outside the loop
+    const bool half_last = S - (ntiles - 1) * 64 <= 32;
+    const int nfull = half_last ? ntiles - 1 : ntiles;
+    for (int t = 0; t < nfull; ++t) {
+        enter(t);
+        if (wave_active) tile(std::integral_constant<int, 2>{}, t);
         if (t < 6) ATTN_STAMP(2 + 2 * t);          // tile t consumed (issue side)
+    }
+    if (half_last) {
+        enter(ntiles - 1);
+        if (wave_active) tile(std::integral_constant<int, 1>{}, ntiles - 1);
     }
     ATTN_STAMP(13);
 
