@@ -16,7 +16,7 @@
 #define GITCAP_ABI_VERSION 1
 // (tools/build_diag.py redefines this to reach the experimental tile kernels of tools/experiments/)
 #ifndef GITCAP_DBG_GEMM_DISPATCH
-#define GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, s) ((tile) == 256 ? launch_gemm256(a, epi, s) : launch_gemm(a, epi, s))
+#define GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, s) ((tile) == 256 ? launch_gemm256(a, epi, s) : (tile) == 64 ? launch_gemm64(a, epi, s) : launch_gemm(a, epi, s))
 #endif
 
 namespace {
@@ -131,14 +131,19 @@ std::string g_create_err;
 const int g_txt_streams = getenv("GITCAP_TXT_STREAMS") ? std::max(1, std::min(4, atoi(getenv("GITCAP_TXT_STREAMS")))) : 2;
 // 256x256-tile count below which the 128x128 kernel is used (GITCAP_GEMM_SMALL_TILES=0 disables the switch)
 const int g_small_tiles = getenv("GITCAP_GEMM_SMALL_TILES") ? atoi(getenv("GITCAP_GEMM_SMALL_TILES")) : 128;
+// 128x128-tile count below which the 64x64 kernel is used (GITCAP_GEMM_TINY_TILES=0 disables the switch)
+const int g_tiny_tiles = getenv("GITCAP_GEMM_TINY_TILES") ? atoi(getenv("GITCAP_GEMM_TINY_TILES")) : 200;     // measured crossover (tools/gemm_tiles_small.py): 180 -> 64x64, 228 -> 128x128
 
 // Tile kernel selection.  Few 256x256 tiles (small batches: one 6-frame clip is 5 x 3..12 tiles for 256 CUs) leave
 // most of the chip idle: below g_small_tiles tiles the 128x128 kernel (4x the workgroups, two per CU) is used
-// (B=1: 7.7 -> 6.8 ms per caption).  All tile kernels produce bitwise identical results
+// (B=1: 7.7 -> 6.8 ms per caption), and below g_tiny_tiles of THOSE the 64x64 kernel (16x, three per CU, 3-stage
+// ring: the single-clip launches).  All tile kernels produce bitwise identical results
 // (tests/test_kernels_gpu.py), so the choice only affects speed.
 hipError_t launch_gemm_auto(const GemmArgs& a, int epi, hipStream_t s) {
-    if (!gemm256_ok(a) || (a.M >> 8) * (a.N >> 8) < g_small_tiles) return launch_gemm(a, epi, s);
-    return launch_gemm256(a, epi, s);
+    if (gemm256_ok(a) && (a.M >> 8) * (a.N >> 8) >= g_small_tiles) return launch_gemm256(a, epi, s);
+    if ((a.M & 63) == 0 && (a.N & 63) == 0 && ((a.M & 127) || (a.N & 127) || (a.M >> 7) * (a.N >> 7) < g_tiny_tiles))
+        return launch_gemm64(a, epi, s);
+    return launch_gemm(a, epi, s);
 }
 
 // OCP e4m3fn code of x, or -1 when x is not exactly representable (bias 7, 3 mantissa bits, max 448, no infinities)
@@ -1019,7 +1024,7 @@ int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float
     a.A = (const bf16_t*)A; a.lda = K; a.W = (const bf16_t*)W; a.bias = bias; a.M = M; a.N = N; a.K = K;
     a.out = out; a.ldo = N; a.resid = resid; a.ldr = N;
     if (epi < 0 || epi > EPI_BIAS_F32) return GITCAP_ERR_ARG;
-    if (tile != 128 && tile != 256) return GITCAP_ERR_ARG;
+    if (tile != 64 && tile != 128 && tile != 256) return GITCAP_ERR_ARG;
     hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, (hipStream_t)stream);
     return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
 }
@@ -1035,7 +1040,7 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
     a.A = (const bf16_t*)A; a.lda = K; a.W = (const bf16_t*)W; a.bias = bias; a.M = M; a.N = N; a.K = K;
     a.out = out_f32; a.ldo = N; a.resid = resid; a.ldr = N;
     if (!fused) {
-        if (tile != 128 && tile != 256) return GITCAP_ERR_ARG;
+        if (tile != 64 && tile != 128 && tile != 256) return GITCAP_ERR_ARG;
         float* xo = out_f32;
         float* tmp = nullptr;
         if (post) { if (hipMalloc(&tmp, (size_t)M * N * 4) != hipSuccess) return GITCAP_ERR_NOMEM; xo = tmp; a.out = tmp; }

@@ -31,6 +31,7 @@ struct GemmArgs {
     unsigned* ln_cnt;             // [M / 256][2] per row block {arrivals, generation}: zero before the first launch, self-resetting
 };
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);      // 128x128 tile (any M%128, N%128)
+hipError_t launch_gemm64(const GemmArgs& a, int epi, hipStream_t s);    // 64x64 tile, 3-stage ring (few-hundred-row launches)
 bool gemm256_ok(const GemmArgs& a);
 hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);   // 256x256 tile, 8-wave ping-pong
 bool gemm256_ln_ok(const GemmArgs& a);                                   // shape the EPI_RESID_LN_* epilogues accept

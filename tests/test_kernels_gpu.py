@@ -25,7 +25,7 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [64, 128, 256])
 @pytest.mark.parametrize("M,N,K,epi", [(512, 768, 768, 0), (256, 256, 64, 4), (768, 2304, 768, 0),
                                        (512, 3072, 768, 1), (512, 3072, 768, 2), (512, 768, 3072, 3),
                                        (256, 1536, 768, 0), (1024, 1024, 1024, 3)])
@@ -57,7 +57,7 @@ def test_gemm_identity_weight_asymmetric_input(lib):
     M = N = K = 256
     A = torch.arange(M * K, device="cuda", dtype=torch.float32).reshape(M, K).remainder(251).bfloat16()
     W = torch.eye(N, K, device="cuda").bfloat16()
-    for tile in (128, 256):
+    for tile in (64, 128, 256):
         out = torch.empty(M, N, device="cuda", dtype=torch.float32)
         assert lib.gitcap_dbg_gemm(_p(A), _p(W), None, None, _p(out), M, N, K, 4, tile, _stream()) == 0
         assert torch.equal(out, A.float())
@@ -75,7 +75,7 @@ def test_gemm_tile_variants_are_bitwise_equal(lib):
     resid = torch.randn(M, N, device="cuda", generator=g)
     for epi, dt in ((0, torch.bfloat16), (1, torch.bfloat16), (3, torch.float32)):
         outs = []
-        for tile in (256, 128):
+        for tile in (256, 128, 64):
             out = torch.empty(M, N, device="cuda", dtype=dt)
             assert lib.gitcap_dbg_gemm(_p(A), _p(W), _p(bias), _p(resid), _p(out), M, N, K, epi, tile, _stream()) == 0
             outs.append(out)
@@ -96,7 +96,7 @@ def test_gemm_layernorm_epilogue_equals_gemm_then_layernorm(lib, M, N, K, post, 
     resid = torch.randn(M, N, device="cuda", generator=g) * 2 + 0.5 if with_resid else None
     gamma, beta = torch.randn(N, device="cuda", generator=g), torch.randn(N, device="cuda", generator=g)
     outs = []
-    for fused, tile in ((1, 256), (0, 256), (0, 128)):
+    for fused, tile in ((1, 256), (0, 256), (0, 128), (0, 64)):
         of = torch.full((M, N), float("nan"), device="cuda")
         ob = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
         for _ in range(2):          # twice: the exchange barrier must be reusable

@@ -26,8 +26,8 @@ patch(os.path.join(dst, 'gemm256.hip'), [
     ("    BARRIER();\n    if (grp == 1) BARRIER();", "    BARRIER();\n    unsigned long long T1 = __builtin_amdgcn_s_memtime();\n    if (grp == 1) BARRIER();"),
     ("    if (grp == 0) BARRIER();                       // matches group 1's extra leading barrier\n",
      "    if (grp == 0) BARRIER();                       // matches group 1's extra leading barrier\n    unsigned long long T2 = __builtin_amdgcn_s_memtime();\n"),
-    ("    gemm_epilogue_wave<EPI>(a, acc, smem + wid * EPI_REGION, m0 + wm * 64, n0 + wn * 128, lane);\n",
-     "    gemm_epilogue_wave<EPI>(a, acc, smem + wid * EPI_REGION, m0 + wm * 64, n0 + wn * 128, lane);\n"
+    ("        gemm_epilogue_wave<EPI>(a, acc, smem + wid * EPI_REGION, m0 + wm * 64, n0 + wn * 128, lane);\n",
+     "        gemm_epilogue_wave<EPI>(a, acc, smem + wid * EPI_REGION, m0 + wm * 64, n0 + wn * 128, lane);\n"
      "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n    unsigned long long T3 = __builtin_amdgcn_s_memtime();\n"
      "    if (EPI != EPI_PATCH_F32 && a.pos && lane == 0) {\n"
      "        unsigned long long* d = (unsigned long long*)a.pos + ((size_t)blockIdx.x * 8 + wid) * 8;\n"
@@ -37,8 +37,9 @@ patch(os.path.join(dst, 'gemm256.hip'), [
      "        d[6] = R0; d[7] = __builtin_amdgcn_s_memrealtime();\n    }\n"),
 ])
 patch(os.path.join(dst, 'gitcap.hip'), [
-    ("    if (tile != 128 && tile != 256) return GITCAP_ERR_ARG;\n", "    if (getenv(\"GEMM_DBG_PTR\")) a.pos = (const float*)strtoull(getenv(\"GEMM_DBG_PTR\"), nullptr, 0);\n"),
-    ("#ifndef GITCAP_DBG_GEMM_DISPATCH\n", "#define GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, s) ((tile) == 258 ? launch_gemm2b(a, epi, s) : (tile) == 257 ? launch_gemm256p(a, epi, s) : (tile) == 256 ? launch_gemm256(a, epi, s) : launch_gemm(a, epi, s))\n#ifndef GITCAP_DBG_GEMM_DISPATCH\n"),
+    ("    if (tile != 64 && tile != 128 && tile != 256) return GITCAP_ERR_ARG;\n    hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, (hipStream_t)stream);",
+     "    if (getenv(\"GEMM_DBG_PTR\")) a.pos = (const float*)strtoull(getenv(\"GEMM_DBG_PTR\"), nullptr, 0);\n    hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, (hipStream_t)stream);"),
+    ("#ifndef GITCAP_DBG_GEMM_DISPATCH\n", "#define GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, s) ((tile) == 258 ? launch_gemm2b(a, epi, s) : (tile) == 257 ? launch_gemm256p(a, epi, s) : (tile) == 256 ? launch_gemm256(a, epi, s) : (tile) == 64 ? launch_gemm64(a, epi, s) : launch_gemm(a, epi, s))\n#ifndef GITCAP_DBG_GEMM_DISPATCH\n"),
 ])
 srcs = 'SRCS=' + ' '.join(sorted(f for f in os.listdir(dst) if f.endswith('.hip')))
 subprocess.check_call(['make', '-C', dst, '-j8', srcs])
