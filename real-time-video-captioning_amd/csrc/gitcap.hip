@@ -66,7 +66,7 @@ struct gitcap {
     unsigned* ln_cnt = nullptr;         // [Mi / 256][2] {arrivals, generation} per 256-row block (self-resetting barrier)
     bf16_t *hb = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr, *patches = nullptr, *kv_img = nullptr;
     // workspace (text rows)
-    float *xs = nullptr, *slabs = nullptr, *part = nullptr, *amax_val = nullptr;
+    float *xs = nullptr, *xs2 = nullptr, *slabs = nullptr, *part = nullptr, *amax_val = nullptr;
     int* amax_idx = nullptr;
     unsigned* row_cnt = nullptr;
     bf16_t *xsb = nullptr, *fs = nullptr, *kv_txt = nullptr, *kv_txt2 = nullptr;
@@ -97,7 +97,7 @@ struct gitcap {
     struct Slot {
         bf16_t* kv_img = nullptr; int32_t* sep_cnt = nullptr;
         // text-row workspace of the slot (token loops of different slots may run concurrently)
-        float *xs = nullptr, *slabs = nullptr, *part = nullptr, *amax_val = nullptr; int* amax_idx = nullptr;
+        float *xs = nullptr, *xs2 = nullptr, *slabs = nullptr, *part = nullptr, *amax_val = nullptr; int* amax_idx = nullptr;
         unsigned* row_cnt = nullptr;
         bf16_t *xsb = nullptr, *fs = nullptr, *kv_txt = nullptr, *kv_txt2 = nullptr;
         int B = 0, S = 0; bool have = false, used = false;
@@ -178,7 +178,7 @@ void select_slot(gitcap* h, int i) {
     o.kv_txt = h->kv_txt; o.kv_txt2 = h->kv_txt2;        // reorder_rows swaps these two
     gitcap::Slot& n = h->slots[i];
     h->kv_img = n.kv_img; h->sep_cnt = n.sep_cnt; h->cur_B = n.B; h->cur_S = n.S; h->have_image = n.have;
-    h->xs = n.xs; h->slabs = n.slabs; h->part = n.part; h->row_cnt = n.row_cnt; h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
+    h->xs = n.xs; h->xs2 = n.xs2; h->slabs = n.slabs; h->part = n.part; h->row_cnt = n.row_cnt; h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
     h->xsb = n.xsb; h->fs = n.fs; h->kv_txt = n.kv_txt; h->kv_txt2 = n.kv_txt2;
     h->cur_slot = i;
 }
@@ -418,25 +418,45 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     if (hid) h->hid_T = T;
     // Per layer 5 launches: [text embedding | reduce of the previous layer's FC2 slabs + LayerNorm], q|k|v projection
     // straight into the text K/V cache, attention + output dense + LayerNorm (txtblock.hip), FC1 + GELU, FC2 as split-K
-    // partial slabs.
+    // partial slabs.  With one or two rows (a single clip: the webcam case) the first of the five runs inside the second
+    // (skinny.hip "row prologue": every workgroup of the q|k|v launch computes the rows itself): 4 launches per layer.
+    // The residual rows then alternate between two buffers (workgroup 0 writes them while the others still read the old).
+    static const bool no_rows_pro = getenv("GITCAP_NO_ROW_PROLOGUE") != nullptr;
+    const bool rows_pro = !no_rows_pro && !hid && skinny_row_prologue_ok(M, D, h->dec[0].qkvw.scale != nullptr);
+    float *xcur = h->xs, *xalt = h->xs2;
     for (int l = 0; l < c.dec_layers; ++l) {
         const DecLayer& L = h->dec[l];
         bf16_t* kvt = h->kv_txt + (size_t)l * kvt_layer;
-        if (l == 0) {
-            HIP_OK(h, launch_embed_text(ids, ld_ids, rows, T, t0, h->word, h->tpos, h->txt_lnw, h->txt_lnb, c.dec_ln_eps, D,
-                                        c.vocab_size, h->xs, h->xsb, s));
+        if (rows_pro) {
+            ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * M * 3 * D * D, 2.0 * 3 * D * D);
+            SkinnyArgs a{h->xsb, D, L.qkvw.p, nullptr, L.qkvb, M, 3 * D, D, kvt, 3 * D, T, h->Tmax, t0, nullptr, nullptr};
+            if (l == 0) {
+                a.ln.kind = 2; a.ln.ids = ids; a.ln.ld_ids = ld_ids; a.ln.T = T; a.ln.t0 = t0; a.ln.vocab = c.vocab_size;
+                a.ln.word = h->word; a.ln.pos = h->tpos; a.ln.g = h->txt_lnw; a.ln.b = h->txt_lnb;
+            } else {
+                const DecLayer& P = h->dec[l - 1];
+                a.ln.kind = 1; a.ln.slabs = h->slabs; a.ln.nslab = ks_f; a.ln.bias = P.fc2b; a.ln.resid = xcur; a.ln.g = P.ln2w; a.ln.b = P.ln2b;
+            }
+            a.ln.eps = c.dec_ln_eps; a.ln.xf = xalt;
+            HIP_OK(h, launch_skinny(a, SK_BIAS_BF16, s));
+            std::swap(xcur, xalt);
         } else {
-            const DecLayer& P = h->dec[l - 1];
-            if ((rc = ln_reduce(h, s, h->slabs, ks_f, P.fc2b, h->xs, P.ln2w, P.ln2b, c.dec_ln_eps, M, D, h->xs, h->xsb))) return rc;
+            if (l == 0) {
+                HIP_OK(h, launch_embed_text(ids, ld_ids, rows, T, t0, h->word, h->tpos, h->txt_lnw, h->txt_lnb, c.dec_ln_eps, D,
+                                            c.vocab_size, xcur, h->xsb, s));
+            } else {
+                const DecLayer& P = h->dec[l - 1];
+                if ((rc = ln_reduce(h, s, h->slabs, ks_f, P.fc2b, xcur, P.ln2w, P.ln2b, c.dec_ln_eps, M, D, xcur, h->xsb))) return rc;
+            }
+            HIP_OK(h, keep_txt(l));
+            if ((rc = skinny(h, s, SK_BIAS_BF16, h->xsb, D, L.qkvw, L.qkvb, M, 3 * D, D, kvt, 3 * D, T, h->Tmax, t0))) return rc;
         }
-        HIP_OK(h, keep_txt(l));
-        if ((rc = skinny(h, s, SK_BIAS_BF16, h->xsb, D, L.qkvw, L.qkvb, M, 3 * D, D, kvt, 3 * D, T, h->Tmax, t0))) return rc;
         {
             TxtBlockArgs ta{};
             ta.kv_img = h->kv_img + (size_t)l * kvi_layer; ta.kv_txt = kvt;
             ta.rows = rows; ta.beams = beams; ta.t0 = t0; ta.T = T; ta.Tmax = h->Tmax; ta.S_img = h->cur_S; ta.H = H; ta.D = D;
-            ta.aow = L.aow.p; ta.aoscale = L.aow.scale; ta.aob = L.aob; ta.g1 = L.ln1w; ta.b1 = L.ln1b; ta.xin = h->xs; ta.eps = c.dec_ln_eps;
-            ta.part = h->part; ta.cnt = h->row_cnt; ta.xs = h->xs; ta.xsb = h->xsb;
+            ta.aow = L.aow.p; ta.aoscale = L.aow.scale; ta.aob = L.aob; ta.g1 = L.ln1w; ta.b1 = L.ln1b; ta.xin = xcur; ta.eps = c.dec_ln_eps;
+            ta.part = h->part; ta.cnt = h->row_cnt; ta.xs = xcur; ta.xsb = h->xsb;
             double kvb = 0;
             for (int j = 0; j < T; ++j) kvb += (double)rows * (h->cur_S + t0 + j + 1) * 2 * D * 2;
             ProfScope ps(h, GITCAP_PROF_ATTN_TEXT, s, 0.0, kvb + (L.aow.scale ? 1.0 : 2.0) * D * D);     // K/V read once + the output dense
@@ -447,7 +467,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     }
     {   // the last layer's FC2 reduce + bias + residual + LayerNorm
         const DecLayer& P = h->dec[c.dec_layers - 1];
-        if ((rc = ln_reduce(h, s, h->slabs, ks_f, P.fc2b, h->xs, P.ln2w, P.ln2b, c.dec_ln_eps, M, D, h->xs, h->xsb))) return rc;
+        if ((rc = ln_reduce(h, s, h->slabs, ks_f, P.fc2b, xcur, P.ln2w, P.ln2b, c.dec_ln_eps, M, D, xcur, h->xsb))) return rc;
         HIP_OK(h, keep_txt(c.dec_layers));
     }
     if (!logits_out && !argmax_out) return 0;
@@ -544,6 +564,7 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
         else rc = rc ? rc : ws_alloc(h, &sl.kv_img, (size_t)c.dec_layers * Mi * 3 * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.sep_cnt, (size_t)h->Tmax + 1);
         rc = rc ? rc : ws_alloc(h, &sl.xs, Mt * h->D);
+        rc = rc ? rc : ws_alloc(h, &sl.xs2, 2 * h->D);            // second copy of the residual rows for the one/two-row form
         rc = rc ? rc : ws_alloc(h, &sl.slabs, (size_t)16 * Mt * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.xsb, Mt * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.part, Mt * (size_t)c.dec_heads * h->D);
@@ -571,7 +592,7 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     }
     if (!rc) {   // select slot 0
         gitcap::Slot& n = h->slots[0];
-        h->sep_cnt = n.sep_cnt; h->xs = n.xs; h->slabs = n.slabs; h->part = n.part; h->row_cnt = n.row_cnt;
+        h->sep_cnt = n.sep_cnt; h->xs = n.xs; h->xs2 = n.xs2; h->slabs = n.slabs; h->part = n.part; h->row_cnt = n.row_cnt;
             h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
         h->xsb = n.xsb; h->fs = n.fs; h->kv_txt = n.kv_txt; h->kv_txt2 = n.kv_txt2;
     }

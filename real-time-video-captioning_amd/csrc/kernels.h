@@ -47,7 +47,21 @@ struct SkinnyArgs {
     void* out;                    // full: row m -> out + orow(m)*ldo, orow(m) = (m / T)*row_stride + row_off + m % T
     int ldo, T, row_stride, row_off;   // splitk: out = fp32 slabs [ksplit][M][ldo]
     float* amax_val; int* amax_idx;    // SK_BIAS_F32 only (nullable): per-tile arg-max partials [M][ntiles]
+    // Optional row prologue (kind != 0; M <= 2, K = the row width, bf16 weights): every workgroup computes the M input rows
+    // itself -- the LayerNorm that would otherwise be the launch in front of this one -- while its weight fragments are
+    // in flight; X is not read.  Workgroup 0 also writes the fp32 rows to xf (must not alias resid).
+    struct RowPrologue {
+        int kind;                          // 0 none, 1 split-K slabs + bias + residual -> LayerNorm, 2 text embedding -> LayerNorm
+        const float* slabs; int nslab;     // kind 1
+        const float *bias, *resid;
+        const int64_t* ids;                // kind 2
+        int ld_ids, T, t0, vocab;
+        const float *word, *pos;
+        const float *g, *b; float eps;     // LayerNorm
+        float* xf;                         // [M][K]
+    } ln;
 };
+bool skinny_row_prologue_ok(int M, int K, bool fp8);         // shapes the row-prologue form is instantiated for
 hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s);
 bool skinny_full_ok(int K);                                  // K depths launch_skinny is instantiated for
 int skinny_ksplit(int K);                                    // number of K slabs launch_skinny_splitk writes

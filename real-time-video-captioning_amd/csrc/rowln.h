@@ -1,0 +1,109 @@
+// Row LayerNorm of the text rows, shared by the stand-alone row kernels (rowops.hip) and by the q|k|v projection that
+// computes its own input rows when there are only one or two of them (skinny.hip, "row prologue"): ONE wave per row, lane
+// holds NV float4 at columns 256 i + 4 lane, two-pass (mean, then centred variance) in registers, fp32 throughout.
+// The same inline code wherever a row is normalised, so the result does not depend on which kernel ran it.
+#pragma once
+#include "common.h"
+
+// v (this lane's values of the row, zero beyond D) and their lane-sum s -> v = LayerNorm(row) * gamma + beta
+template <int NV>
+__device__ __forceinline__ void row_layernorm(f32x4 (&v)[NV], const float s, const int lane, const int D, const float eps,
+                                              const float* __restrict__ gamma, const float* __restrict__ beta) {
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+            const f32x4 g = *(const f32x4*)(gamma + c);
+            const f32x4 b = *(const f32x4*)(beta + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+        }
+    }
+}
+
+// v = sum_k slab[k][m] (fixed order) + bias + resid[m]; returns the lane-sum
+template <int NV>
+__device__ __forceinline__ float row_load_reduce(f32x4 (&v)[NV], const float* __restrict__ slabs, const int nslab,
+                                                 const float* __restrict__ bias, const float* __restrict__ resid,
+                                                 const int M, const int D, const int m, const int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // 8 slabs x NV vectors are requested before the first add (no serial latency chain); the
+    // summation order is fixed, so the result does not depend on launch geometry or timing
+    for (int k0 = 0; k0 < nslab; k0 += 8) {
+        f32x4 p[8][NV];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = i * 256 + lane * 4;
+                p[k][i] = (k0 + k < nslab && c < D) ? *(const f32x4*)(slabs + ((size_t)(k0 + k) * M + m) * D + c)
+                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            v[i] += ((p[0][i] + p[1][i]) + (p[2][i] + p[3][i])) + ((p[4][i] + p[5][i]) + (p[6][i] + p[7][i]));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+            v[i] += *(const f32x4*)(bias + c) + *(const f32x4*)(resid + (size_t)m * D + c);
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+    }
+    return s;
+}
+
+// v = word[ids[r*ld_ids + j]] + pos[t0 + j], m = r*T + j; returns the lane-sum
+template <int NV>
+__device__ __forceinline__ float row_load_embed(f32x4 (&v)[NV], const int64_t* __restrict__ ids, const int ld_ids,
+                                                const int T, const int t0, const float* __restrict__ word,
+                                                const float* __restrict__ pos, const int D, const int vocab, const int m,
+                                                const int lane) {
+    const int r = m / T, j = m - r * T;
+    int64_t tok = ids[(size_t)r * ld_ids + j];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);          // never index outside the table
+    const float* wr = word + (size_t)tok * D;
+    const float* pr = pos + (size_t)(t0 + j) * D;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+            v[i] = *(const f32x4*)(wr + c) + *(const f32x4*)(pr + c);
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        } else v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    return s;
+}
+
+// fp32 and/or bf16 copies of the row (either pointer may be null)
+template <int NV>
+__device__ __forceinline__ void row_store(const f32x4 (&y)[NV], const int lane, const int D, float* xf_row, bf16_t* xb_row) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        if (c < D) {
+            if (xf_row) *(f32x4*)(xf_row + c) = y[i];
+            if (xb_row) {
+                uint2 o;
+                o.x = pack_bf2(y[i][0], y[i][1]);
+                o.y = pack_bf2(y[i][2], y[i][3]);
+                *(uint2*)(xb_row + c) = o;
+            }
+        }
+    }
+}

@@ -2,6 +2,7 @@
 // (im2col of NCHW fp32 frames, coalesced 16-B reads along W), text embedding, argmax.
 #include "kernels.h"
 #include "ln_canon.h"
+#include "rowln.h"
 
 namespace {
 
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void dequant_fp8_kernel(const unsigned char* _
     *(uint4*)(out + e + 8) = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
-// ---- text embedding + LayerNorm: one wave per (row, position) ----------------------------------
+// ---- text embedding + LayerNorm: one wave per (row, position) (rowln.h) --------------------------
 template <int NV>
 __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restrict__ ids, int ld_ids, int rows, int T,
                                                          int t0, const float* __restrict__ word,
@@ -167,51 +168,13 @@ __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restri
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= rows * T) return;
-    const int r = m / T, j = m - r * T;
-    int64_t tok = ids[(size_t)r * ld_ids + j];
-    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);          // never index outside the table
-    const float* wr = word + (size_t)tok * D;
-    const float* pr = pos + (size_t)(t0 + j) * D;
     f32x4 v[NV];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = i * 256 + lane * 4;
-        if (c < D) {
-            v[i] = *(const f32x4*)(wr + c) + *(const f32x4*)(pr + c);
-            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-        } else v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = i * 256 + lane * 4;
-        if (c < D) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = i * 256 + lane * 4;
-        if (c < D) {
-            const f32x4 g = *(const f32x4*)(gamma + c);
-            const f32x4 b = *(const f32x4*)(beta + c);
-            f32x4 y;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-            *(f32x4*)(xf + (size_t)m * D + c) = y;
-            uint2 o;
-            o.x = pack_bf2(y[0], y[1]);
-            o.y = pack_bf2(y[2], y[3]);
-            *(uint2*)(xb + (size_t)m * D + c) = o;
-        }
-    }
+    const float s = row_load_embed<NV>(v, ids, ld_ids, T, t0, word, pos, D, vocab, m, lane);
+    row_layernorm<NV>(v, s, lane, D, eps, gamma, beta);
+    row_store<NV>(v, lane, D, xf + (size_t)m * D, xb + (size_t)m * D);
 }
 
-// ---- split-K reduce + bias + residual + LayerNorm (text rows): one wave per row ----------------
+// ---- split-K reduce + bias + residual + LayerNorm (text rows): one wave per row (rowln.h) -------
 template <int NV>
 __global__ __launch_bounds__(64) void ln_reduce_kernel(const float* __restrict__ slabs, int nslab,
                                                        const float* __restrict__ bias, const float* __restrict__ resid,
@@ -220,60 +183,9 @@ __global__ __launch_bounds__(64) void ln_reduce_kernel(const float* __restrict__
                                                        bf16_t* __restrict__ xb) {
     const int lane = threadIdx.x, m = blockIdx.x;
     f32x4 v[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // 8 slabs x NV vectors are requested before the first add (no serial latency chain); the
-    // summation order is fixed, so the result does not depend on launch geometry or timing
-    for (int k0 = 0; k0 < nslab; k0 += 8) {
-        f32x4 p[8][NV];
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int c = i * 256 + lane * 4;
-                p[k][i] = (k0 + k < nslab && c < D) ? *(const f32x4*)(slabs + ((size_t)(k0 + k) * M + m) * D + c)
-                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            v[i] += ((p[0][i] + p[1][i]) + (p[2][i] + p[3][i])) + ((p[4][i] + p[5][i]) + (p[6][i] + p[7][i]));
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = i * 256 + lane * 4;
-        if (c < D) {
-            v[i] += *(const f32x4*)(bias + c) + *(const f32x4*)(resid + (size_t)m * D + c);
-            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-        }
-    }
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = i * 256 + lane * 4;
-        if (c < D) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = i * 256 + lane * 4;
-        if (c < D) {
-            const f32x4 g = *(const f32x4*)(gamma + c);
-            const f32x4 b = *(const f32x4*)(beta + c);
-            f32x4 y;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-            *(f32x4*)(xf + (size_t)m * D + c) = y;
-            uint2 o;
-            o.x = pack_bf2(y[0], y[1]);
-            o.y = pack_bf2(y[2], y[3]);
-            *(uint2*)(xb + (size_t)m * D + c) = o;
-        }
-    }
+    const float s = row_load_reduce<NV>(v, slabs, nslab, bias, resid, M, D, m, lane);
+    row_layernorm<NV>(v, s, lane, D, eps, gamma, beta);
+    row_store<NV>(v, lane, D, xf + (size_t)m * D, xb + (size_t)m * D);
 }
 
 // ---- final arg-max over the per-tile partials written by the vocabulary-head kernel ------------

@@ -16,7 +16,15 @@
 //                  partial tile to a slab; ln_reduce_kernel (rowops.hip) sums the slabs in a fixed
 //                  order, adds bias + residual and applies LayerNorm.  No atomics: results are
 //                  bitwise reproducible and independent of the batch size.
+//
+// Row prologue (LNR, one or two text rows: the single-clip case): the token loop is a chain of dependent launches of
+// ~5 us each, and with one row the launch that only normalises it costs as much as one that streams a matrix.  With
+// LNR every workgroup of the q|k|v launch computes the row(s) itself (rowln.h: the code of the stand-alone kernels, so
+// the same bits) right after requesting its weight fragments -- the two latencies overlap -- and keeps them in LDS;
+// 24 KB of slabs per row, read by 144 workgroups through L2, is nothing.  (For more rows the redundant reads and the
+// serial row loop cost more than the launch.)
 #include "kernels.h"
+#include "rowln.h"
 
 namespace {
 
@@ -39,13 +47,37 @@ __device__ __forceinline__ void load_wfrags(const void* W, const float* wscale, 
     }
 }
 
-template <int K32, int EPI, bool FP8>
+template <int K32, int EPI, bool FP8, bool LNR>
 __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
     const int lane = threadIdx.x;
     const int frow = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * 16;
     bf16x8 wf[K32];
     load_wfrags<K32, FP8>(a.W, a.wscale, (size_t)(n0 + frow), a.K, fq * 8, wf);
+    __shared__ __attribute__((aligned(16))) bf16_t xrow[LNR ? 2 : 1][LNR ? K32 * 32 : 8];
+    if (LNR) {
+        constexpr int NV = (K32 * 32 + 255) / 256;
+        const SkinnyArgs::RowPrologue& p = a.ln;
+        for (int m = 0; m < a.M; ++m) {
+            f32x4 v[NV];
+            const float s = p.kind == 1 ? row_load_reduce<NV>(v, p.slabs, p.nslab, p.bias, p.resid, a.M, a.K, m, lane)
+                                        : row_load_embed<NV>(v, p.ids, p.ld_ids, p.T, p.t0, p.word, p.pos, a.K, p.vocab, m, lane);
+            row_layernorm<NV>(v, s, lane, a.K, p.eps, p.g, p.b);
+            row_store<NV>(v, lane, a.K, blockIdx.x == 0 ? p.xf + (size_t)m * a.K : nullptr, (bf16_t*)nullptr);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = i * 256 + lane * 4;
+                if (c < K32 * 32) {
+                    uint2 o;
+                    o.x = pack_bf2(v[i][0], v[i][1]);
+                    o.y = pack_bf2(v[i][2], v[i][3]);
+                    *(uint2*)(&xrow[m][c]) = o;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
 
     const int n = n0 + fq * 4;
     float bias[4];
@@ -61,7 +93,7 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < K32; ++k) {
-            const bf16x8 xf = *(const bf16x8*)(xp + k * 32);
+            const bf16x8 xf = LNR ? *(const bf16x8*)(&xrow[m][fq * 8 + k * 32]) : *(const bf16x8*)(xp + k * 32);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k], xf, acc, 0, 0, 0);
         }
         // lane holds out[m][n .. n+3]
@@ -148,13 +180,26 @@ __global__ __launch_bounds__(64) void skinny_splitk_kernel(SkinnyArgs a) {
 template <int K32, bool FP8>
 hipError_t launch_full(const SkinnyArgs& a, int epi, hipStream_t s) {
     const int grid = (a.N + 15) / 16;
+    if (a.ln.kind) return hipErrorInvalidValue;          // row prologue: launch_full_rows
     switch (epi) {
-        case SK_BIAS_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16, FP8>), dim3(grid), dim3(64), 0, s, a); break;
-        case SK_BIAS_GELU_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_GELU_BF16, FP8>), dim3(grid), dim3(64), 0, s, a); break;
-        case SK_BIAS_RELU_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_RELU_BF16, FP8>), dim3(grid), dim3(64), 0, s, a); break;
-        case SK_BIAS_F32: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_F32, FP8>), dim3(grid), dim3(64), 0, s, a); break;
+        case SK_BIAS_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16, FP8, false>), dim3(grid), dim3(64), 0, s, a); break;
+        case SK_BIAS_GELU_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_GELU_BF16, FP8, false>), dim3(grid), dim3(64), 0, s, a); break;
+        case SK_BIAS_RELU_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_RELU_BF16, FP8, false>), dim3(grid), dim3(64), 0, s, a); break;
+        case SK_BIAS_F32: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_F32, FP8, false>), dim3(grid), dim3(64), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// with the row prologue: the q|k|v projection of one or two text rows
+template <int K32>
+hipError_t launch_full_rows(const SkinnyArgs& a, int epi, hipStream_t s) {
+    const SkinnyArgs::RowPrologue& p = a.ln;
+    if (epi != SK_BIAS_BF16 || !skinny_row_prologue_ok(a.M, a.K, a.wscale != nullptr) || !p.g || !p.b || !p.xf ||
+        (p.kind == 1 && (!p.slabs || p.nslab <= 0 || !p.bias || !p.resid || p.resid == p.xf)) ||
+        (p.kind == 2 && (!p.ids || p.T <= 0 || !p.word || !p.pos)) || (p.kind != 1 && p.kind != 2))
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16, false, true>), dim3((a.N + 15) / 16), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
@@ -165,8 +210,11 @@ bool skinny_full_ok(int K) {
     return K % 32 == 0 && (k32 == 2 || k32 == 4 || k32 == 8 || k32 == 18 || k32 == 24 || k32 == 32);
 }
 
+bool skinny_row_prologue_ok(int M, int K, bool fp8) { return M >= 1 && M <= 2 && (K == 128 || K == 768) && !fp8; }
+
 hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s) {
     if (a.K % 32 || a.M <= 0 || a.T <= 0) return hipErrorInvalidValue;
+    if (a.ln.kind) return a.K == 128 ? launch_full_rows<4>(a, epi, s) : launch_full_rows<24>(a, epi, s);
     if (a.wscale) {                                     // e4m3 weights (GIT decoder widths only)
         switch (a.K / 32) {
             case 4: return launch_full<4, true>(a, epi, s);
