@@ -251,7 +251,9 @@ def main():
         model.profile(False)
         breakdown = {k: {"ms_per_step": round(v["ms"] / nprof, 4), "launches_per_step": v["launches"] // nprof}
                      for k, v in prof.items()}
-        gm = prof["gemm"]
+        # every big-tile GEMM launch: the plain epilogues + the residual GEMMs that also normalise their output rows
+        gp, gl = prof["gemm"], prof["gemm_ln"]
+        gm = {k: gp[k] + gl[k] for k in ("ms", "launches", "flops")}
         avg_ms = gm["ms"] / max(1, gm["launches"])
         achieved = gm["flops"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
         # HBM-side bytes per launch of this kernel come from separate rocprofv3 --pmc passes (FETCH_SIZE,
@@ -274,6 +276,11 @@ def main():
                     # the residual GEMMs normalise their own output rows (EPI_RESID_LN_*): their brackets contain what used
                     # to be separate launches of the layernorm class (37 per step before; what is left is counted here)
                     "layernorm_launches_per_step": prof["rowops"]["launches"] // nprof}
+        def part(v):
+            t = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
+            return {"launches_per_step": v["launches"] // nprof, "avg_launch_ms": round(v["ms"] / max(1, v["launches"]), 4),
+                    "achieved": round(t, 1), "frac": round(t / MFMA_PEAK_TFLOPS, 4)}
+        roofline["by_epilogue"] = {"plain (bias / GELU / residual)": part(gp), "residual + LayerNorm of the output rows": part(gl)}
         def rate(cls, key, scale):
             v = prof[cls]
             return round(v[key] / (v["ms"] * 1e-3) / scale, 1) if v["ms"] > 0 and v[key] > 0 else None

@@ -197,8 +197,9 @@ enum {
     GITCAP_PROF_ATTN_FULL = 1,  /* flash attention over frames / image prefix */
     GITCAP_PROF_SKINNY = 2,     /* text-row weight-streaming GEMMs (incl. vocabulary head) and their reduce+LayerNorm */
     GITCAP_PROF_ATTN_TEXT = 3,  /* text-row attention over the KV cache */
-    GITCAP_PROF_ROWOPS = 4,     /* LayerNorm over the image rows */
-    GITCAP_PROF_CLASSES = 5
+    GITCAP_PROF_ROWOPS = 4,     /* LayerNorm over the image rows (launches of its own) */
+    GITCAP_PROF_GEMM_LN = 5,    /* the residual GEMMs that also normalise their output rows (counted here, not in class 0) */
+    GITCAP_PROF_CLASSES = 6
 };
 int gitcap_profile_enable(gitcap_t* h, int enable);
 int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launches,

@@ -326,7 +326,7 @@ int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const
     if (g_fuse_ln && alias_ok && gemm256_ln_ok(a) && (M >> 8) * (N >> 8) >= g_small_tiles && (post || resid)) {
         a.W = stage_weight(h, s, W, N, K, &e);
         HIP_OK(h, e);
-        ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * h->prof_rows * N * K, 0.0);
+        ProfScope ps(h, GITCAP_PROF_GEMM_LN, s, 2.0 * h->prof_rows * N * K, 0.0);
         HIP_OK(h, launch_gemm256(a, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s));
         return 0;
     }

@@ -545,7 +545,7 @@ class GitCaptioner(nn.Module):
         with torch.cuda.device(self._dev):
             self._call("gitcap_reorder_rows", ctypes.c_void_p(idx.data_ptr()), idx.numel(), t_len, self._stream())
 
-    PROF_CLASSES = ("gemm", "attn_full", "skinny", "attn_text", "rowops")
+    PROF_CLASSES = ("gemm", "attn_full", "skinny", "attn_text", "rowops", "gemm_ln")
 
     def profile(self, enable: bool):
         self._call("gitcap_profile_enable", int(bool(enable)))
