@@ -116,9 +116,15 @@ def main():
     dev = torch.device("cuda", local)
     dist = None
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the latter: 1-rank rehearsal of the N>1 path
+    json_fd = None
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL prints a version banner to stdout when its communicator is created: keep the process's stdout for the ONE
+        # JSON line (everything else written to fd 1 from here on goes to stderr)
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     from gitcap.config import git_base
@@ -318,7 +324,10 @@ def main():
             "caption_mfma_frac": round(value / world * GFLOP_PER_CAPTION / 1e3 / MFMA_PEAK_TFLOPS, 4),
             "serial": serial, "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown,
         }
-        print(json.dumps(line), flush=True)
+        if json_fd is not None:
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+        else:
+            print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
 
