@@ -282,10 +282,15 @@ def main():
                     # the residual GEMMs normalise their own output rows (EPI_RESID_LN_*): their brackets contain what used
                     # to be separate launches of the layernorm class (37 per step before; what is left is counted here)
                     "layernorm_launches_per_step": prof["rowops"]["launches"] // nprof}
-        def part(v):
+        def part(v):    # both roofs of a launch class: a residual epilogue moves 4-10 bytes per output element
             t = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0
+            g = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0
+            floor_ms = [v["flops"] / (MFMA_PEAK_TFLOPS * 1e12) * 1e3, v["bytes"] / (HBM_PEAK_GBS * 1e9) * 1e3]
             return {"launches_per_step": v["launches"] // nprof, "avg_launch_ms": round(v["ms"] / max(1, v["launches"]), 4),
-                    "achieved": round(t, 1), "frac": round(t / MFMA_PEAK_TFLOPS, 4)}
+                    "achieved": round(t, 1), "frac": round(t / MFMA_PEAK_TFLOPS, 4),
+                    "algorithmic_gbytes_per_s": round(g, 1), "hbm_frac": round(g / HBM_PEAK_GBS, 4),
+                    "binding_roof": "mfma" if floor_ms[0] >= floor_ms[1] else "hbm",
+                    "frac_of_binding_roof": round(max(floor_ms) / v["ms"], 4) if v["ms"] > 0 else None}
         roofline["by_epilogue"] = {"plain (bias / GELU / residual)": part(gp), "residual + LayerNorm of the output rows": part(gl)}
         def rate(cls, key, scale):
             v = prof[cls]

@@ -296,8 +296,10 @@ int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef
     hipError_t e;
     const bf16_t* Wb = stage_weight(h, s, W, N, K, &e);
     HIP_OK(h, e);
-    // algorithmic work: the VALID rows (h->prof_rows), not the 128-padded M that is launched
-    ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * h->prof_rows * N * K, 0.0);
+    // algorithmic work: the VALID rows (h->prof_rows), not the 128-padded M that is launched; bytes = operands once +
+    // the output (+ the fp32 residual read)
+    const double R = h->prof_rows, osz = (epi == EPI_BIAS_RESID_F32 || epi == EPI_BIAS_F32 || epi == EPI_PATCH_F32) ? 4.0 : 2.0;
+    ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * R * N * K, 2.0 * R * K + 2.0 * N * K + R * N * (osz + (resid ? 4.0 : 0.0)));
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = Wb; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
     a.resid = resid; a.ldr = ldr;
@@ -326,7 +328,8 @@ int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const
     if (g_fuse_ln && alias_ok && gemm256_ln_ok(a) && (M >> 8) * (N >> 8) >= g_small_tiles && (post || resid)) {
         a.W = stage_weight(h, s, W, N, K, &e);
         HIP_OK(h, e);
-        ProfScope ps(h, GITCAP_PROF_GEMM_LN, s, 2.0 * h->prof_rows * N * K, 0.0);
+        const double R = h->prof_rows;      // A + W + fp32 out + bf16 LayerNorm out (+ fp32 residual read)
+        ProfScope ps(h, GITCAP_PROF_GEMM_LN, s, 2.0 * R * N * K, 2.0 * R * K + 2.0 * N * K + R * N * (6.0 + (resid ? 4.0 : 0.0)));
         HIP_OK(h, launch_gemm256(a, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s));
         return 0;
     }
@@ -792,7 +795,7 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
         hipError_t e;
         const bf16_t* Wb = stage_weight(h, s, h->patch_w, Dv, h->Kp, &e);
         HIP_OK(h, e);
-        ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * P * Dv * (3.0 * c.patch_size * c.patch_size), 0.0);
+        ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * P * Dv * (3.0 * c.patch_size * c.patch_size), 2.0 * P * h->Kp + 2.0 * Dv * h->Kp + 4.0 * P * Dv);
         GemmArgs a{};
         a.A = h->patches; a.lda = h->Kp; a.W = Wb; a.bias = nullptr; a.M = Pp; a.N = Dv; a.K = h->Kp;
         a.out = h->x; a.ldo = Dv; a.pos = h->pos; a.tokens_per_frame = N; a.patches_per_frame = h->G * h->G; a.valid_rows = P;

@@ -191,15 +191,18 @@ hipError_t launch_full(const SkinnyArgs& a, int epi, hipStream_t s) {
     return hipGetLastError();
 }
 
-// with the row prologue: the q|k|v projection of one or two text rows
+// with the row prologue: a bf16-output projection of one or two text rows (GIT q|k|v; the student's q|k|v, cross q, FC1)
 template <int K32>
 hipError_t launch_full_rows(const SkinnyArgs& a, int epi, hipStream_t s) {
     const SkinnyArgs::RowPrologue& p = a.ln;
-    if (epi != SK_BIAS_BF16 || !skinny_row_prologue_ok(a.M, a.K, a.wscale != nullptr) || !p.g || !p.b || !p.xf ||
+    if (!skinny_row_prologue_ok(a.M, a.K, a.wscale != nullptr) || !p.g || !p.b || !p.xf ||
         (p.kind == 1 && (!p.slabs || p.nslab <= 0 || !p.bias || !p.resid || p.resid == p.xf)) ||
         (p.kind == 2 && (!p.ids || p.T <= 0 || !p.word || !p.pos)) || (p.kind != 1 && p.kind != 2))
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16, false, true>), dim3((a.N + 15) / 16), dim3(64), 0, s, a);
+    const dim3 grid((a.N + 15) / 16);
+    if (epi == SK_BIAS_BF16) hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16, false, true>), grid, dim3(64), 0, s, a);
+    else if (epi == SK_BIAS_RELU_BF16) hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_RELU_BF16, false, true>), grid, dim3(64), 0, s, a);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -210,11 +213,13 @@ bool skinny_full_ok(int K) {
     return K % 32 == 0 && (k32 == 2 || k32 == 4 || k32 == 8 || k32 == 18 || k32 == 24 || k32 == 32);
 }
 
-bool skinny_row_prologue_ok(int M, int K, bool fp8) { return M >= 1 && M <= 2 && (K == 128 || K == 768) && !fp8; }
+bool skinny_row_prologue_ok(int M, int K, bool fp8) { return M >= 1 && M <= 2 && (K == 64 || K == 128 || K == 576 || K == 768) && !fp8; }
 
 hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s) {
     if (a.K % 32 || a.M <= 0 || a.T <= 0) return hipErrorInvalidValue;
-    if (a.ln.kind) return a.K == 128 ? launch_full_rows<4>(a, epi, s) : launch_full_rows<24>(a, epi, s);
+    if (a.ln.kind)
+        return a.K == 64 ? launch_full_rows<2>(a, epi, s) : a.K == 128 ? launch_full_rows<4>(a, epi, s)
+             : a.K == 576 ? launch_full_rows<18>(a, epi, s) : launch_full_rows<24>(a, epi, s);
     if (a.wscale) {                                     // e4m3 weights (GIT decoder widths only)
         switch (a.K / 32) {
             case 4: return launch_full<4, true>(a, epi, s);

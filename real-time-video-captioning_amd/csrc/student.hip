@@ -111,7 +111,7 @@ struct gitcap_student {
     std::vector<void*> allocs;
     int64_t ws_bytes = 0;
     // workspace: text rows
-    float *xf = nullptr, *slabs = nullptr, *amax_val = nullptr;
+    float *xf = nullptr, *xf2 = nullptr, *slabs = nullptr, *amax_val = nullptr;
     int* amax_idx = nullptr;
     bf16_t *xb = nullptr, *qc = nullptr, *ctx = nullptr, *ffn = nullptr, *kvs = nullptr, *memb = nullptr, *memkv = nullptr;
     int32_t* sep_cnt = nullptr;
@@ -193,16 +193,6 @@ int sk_full(gitcap_student* h, hipStream_t s, int epi, const bf16_t* X, int ldx,
     return 0;
 }
 
-// x = LayerNorm(x + X.W^T + bias): split-K partial slabs, then sum + bias + residual + LayerNorm in one row kernel
-int dense_add_ln(gitcap_student* h, hipStream_t s, const bf16_t* X, int K, const bf16_t* W, const float* bias,
-                 const float* g, const float* b, int M) {
-    SkinnyArgs a{};
-    a.X = X; a.ldx = K; a.W = W; a.M = M; a.N = h->D; a.K = K; a.out = h->slabs; a.ldo = h->D; a.T = 1; a.row_stride = 1;
-    S_HIP_OK(h, launch_skinny_splitk(a, s));
-    S_HIP_OK(h, launch_ln_reduce(h->slabs, skinny_ksplit(K), bias, h->xf, g, b, h->c.ln_eps, M, h->D, h->xf, h->xb, s));
-    return 0;
-}
-
 // model.py:128-154 for rows x T query positions t0..t0+T-1 (K/V of earlier positions come from the cache)
 int text_forward(gitcap_student* h, const int64_t* ids, int ld_ids, int rows, int t0, int T, float* logits_out,
                  int64_t* argmax_out, int ld_argmax, int32_t* sep_cnt, int step, hipStream_t s) {
@@ -217,24 +207,53 @@ int text_forward(gitcap_student* h, const int64_t* ids, int ld_ids, int rows, in
     int rc;
     S_HIP_OK(h, launch_student_embed(ids, ld_ids, rows, T, t0, h->embed, h->pe, D, h->V, h->xf, h->xb, s));
     const size_t kvs_layer = (size_t)h->R * h->Tmax * 3 * D, mem_layer = (size_t)h->R * h->F * 2 * D;
+    // Each post-LN sub-layer is split-K partial slabs -> sum + bias + residual + LayerNorm.  With one or two rows (the webcam
+    // case) that row kernel is not launched: the projection that consumes its output computes the rows itself (skinny.hip
+    // "row prologue", same code -> same bits) and workgroup 0 writes the fp32 residual rows to the other of two buffers.
+    static const bool no_rows_pro = getenv("GITCAP_NO_ROW_PROLOGUE") != nullptr;
+    const bool rows_pro = !no_rows_pro && skinny_row_prologue_ok(M, D, false);
+    float *xcur = h->xf, *xalt = h->xf2;
+    struct { bool on; const float *bias, *g, *b; int nslab; } pend{false, nullptr, nullptr, nullptr, 0};
+    // out = epi(LN-output . W^T + bias): the LN output is xb, or -- when a reduce + LayerNorm is pending -- computed in place
+    auto proj = [&](int epi, const bf16_t* W, const float* bias, int N, void* out, int ldo, int Tq, int row_stride, int row_off) -> int {
+        if (!pend.on) return sk_full(h, s, epi, h->xb, D, W, bias, M, N, D, out, ldo, Tq, row_stride, row_off);
+        SkinnyArgs a{};
+        a.X = h->xb; a.ldx = D; a.W = W; a.bias = bias; a.M = M; a.N = N; a.K = D; a.out = out; a.ldo = ldo;
+        a.T = Tq; a.row_stride = row_stride; a.row_off = row_off;
+        a.ln.kind = 1; a.ln.slabs = h->slabs; a.ln.nslab = pend.nslab; a.ln.bias = pend.bias; a.ln.resid = xcur;
+        a.ln.g = pend.g; a.ln.b = pend.b; a.ln.eps = h->c.ln_eps; a.ln.xf = xalt;
+        S_HIP_OK(h, launch_skinny(a, epi, s));
+        std::swap(xcur, xalt);
+        pend.on = false;
+        return 0;
+    };
+    // x = LayerNorm(x + X.W^T + bias): split-K partial slabs, then the row kernel now or (defer) inside the next projection
+    auto dense_ln = [&](const bf16_t* X, int K, const bf16_t* W, const float* bias, const float* g, const float* b, bool defer) -> int {
+        SkinnyArgs a{};
+        a.X = X; a.ldx = K; a.W = W; a.M = M; a.N = D; a.K = K; a.out = h->slabs; a.ldo = D; a.T = 1; a.row_stride = 1;
+        S_HIP_OK(h, launch_skinny_splitk(a, s));
+        if (rows_pro && defer) { pend = {true, bias, g, b, skinny_ksplit(K)}; return 0; }
+        S_HIP_OK(h, launch_ln_reduce(h->slabs, skinny_ksplit(K), bias, xcur, g, b, h->c.ln_eps, M, D, xcur, h->xb, s));
+        return 0;
+    };
     for (int l = 0; l < h->L; ++l) {
         const StuLayer& Ly = h->layers[l];
         bf16_t* kv = h->kvs + (size_t)l * kvs_layer;
         // self-attention: q | k | v of the new positions go straight into the cache rows (r, t0 + j)
-        if ((rc = sk_full(h, s, SK_BIAS_BF16, h->xb, D, Ly.sa_in_w, Ly.sa_in_b, M, 3 * D, D, kv, 3 * D, T, h->Tmax, t0))) return rc;
+        if ((rc = proj(SK_BIAS_BF16, Ly.sa_in_w, Ly.sa_in_b, 3 * D, kv, 3 * D, T, h->Tmax, t0))) return rc;
         SmallAttnArgs sa{kv, 3 * D, T, h->Tmax, t0, kv + D, kv + 2 * D, 3 * D, h->Tmax, 0, t0,
                          ids, ld_ids, c.pad_token_id, h->ctx, D, M, h->H, h->hd};
         S_HIP_OK(h, launch_attn_small(sa, s));
-        if ((rc = dense_add_ln(h, s, h->ctx, D, Ly.sa_out_w, Ly.sa_out_b, Ly.n1w, Ly.n1b, M))) return rc;
+        if ((rc = dense_ln(h->ctx, D, Ly.sa_out_w, Ly.sa_out_b, Ly.n1w, Ly.n1b, true))) return rc;
         // cross-attention over the frame tokens (K/V precomputed by set_memory)
-        if ((rc = sk_full(h, s, SK_BIAS_BF16, h->xb, D, Ly.ca_in_w, Ly.ca_in_b, M, D, D, h->qc, D))) return rc;
+        if ((rc = proj(SK_BIAS_BF16, Ly.ca_in_w, Ly.ca_in_b, D, h->qc, D, 1, 1, 0))) return rc;
         const bf16_t* mkv = h->memkv + (size_t)l * mem_layer;
         SmallAttnArgs ca{h->qc, D, T, T, 0, mkv, mkv + D, 2 * D, h->F, h->F, 0, nullptr, 0, 0, h->ctx, D, M, h->H, h->hd};
         S_HIP_OK(h, launch_attn_small(ca, s));
-        if ((rc = dense_add_ln(h, s, h->ctx, D, Ly.ca_out_w, Ly.ca_out_b, Ly.n2w, Ly.n2b, M))) return rc;
-        // feed-forward
-        if ((rc = sk_full(h, s, SK_BIAS_RELU_BF16, h->xb, D, Ly.l1w, Ly.l1b, M, h->FF, D, h->ffn, h->FF))) return rc;
-        if ((rc = dense_add_ln(h, s, h->ffn, h->FF, Ly.l2w, Ly.l2b, Ly.n3w, Ly.n3b, M))) return rc;
+        if ((rc = dense_ln(h->ctx, D, Ly.ca_out_w, Ly.ca_out_b, Ly.n2w, Ly.n2b, true))) return rc;
+        // feed-forward (the last layer's LayerNorm is a launch: the vocabulary head reads its bf16 output)
+        if ((rc = proj(SK_BIAS_RELU_BF16, Ly.l1w, Ly.l1b, h->FF, h->ffn, h->FF, 1, 1, 0))) return rc;
+        if ((rc = dense_ln(h->ffn, h->FF, Ly.l2w, Ly.l2b, Ly.n3w, Ly.n3b, l + 1 < h->L))) return rc;
     }
     if (!logits_out && !argmax_out) return 0;
     // vocabulary head: all positions when logits are requested, else the last position of every row
@@ -382,7 +401,7 @@ int gitcap_student_finalize(gitcap_student_t* h) {
         const int ks = std::max(skinny_ksplit(h->D), skinny_ksplit(h->FF));
         const size_t ntiles = ((size_t)h->V + 15) / 16;
         int rc;
-        if ((rc = s_alloc(h, &h->xf, Mt * D)) || (rc = s_alloc(h, &h->xb, Mt * D)) || (rc = s_alloc(h, &h->qc, Mt * D)) ||
+        if ((rc = s_alloc(h, &h->xf2, 2 * D)) || (rc = s_alloc(h, &h->xf, Mt * D)) || (rc = s_alloc(h, &h->xb, Mt * D)) || (rc = s_alloc(h, &h->qc, Mt * D)) ||
             (rc = s_alloc(h, &h->ctx, Mt * D)) || (rc = s_alloc(h, &h->ffn, Mt * h->FF)) ||
             (rc = s_alloc(h, &h->slabs, (size_t)ks * Mt * D)) || (rc = s_alloc(h, &h->amax_val, Mt * ntiles)) ||
             (rc = s_alloc(h, &h->amax_idx, Mt * ntiles)) || (rc = s_alloc(h, &h->kvs, (size_t)h->L * Mt * 3 * D)) ||
