@@ -75,6 +75,7 @@ struct gitcap {
     float* beam_logits = nullptr;       // [R][V]
     float* cand_scores = nullptr;       // [B][16]
     int* cand_idx = nullptr;
+    char* topk_scratch = nullptr;       // beam_topk chunk statistics + per-chunk candidates (sized for max_batch x max_beams rows)
 
     // resolved weights
     WRef patch_w, vproj_w, head_w;
@@ -592,6 +593,7 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
         rc = rc ? rc : ws_alloc(h, &h->beam_logits, R * (size_t)h->V);
         rc = rc ? rc : ws_alloc(h, &h->cand_scores, Bm * 16);
         rc = rc ? rc : ws_alloc(h, &h->cand_idx, Bm * 16);
+        rc = rc ? rc : ws_alloc(h, &h->topk_scratch, beam_topk_scratch_bytes(c.max_batch, std::max(1, c.max_beams), h->V, 16));
     }
     if (!rc) {   // select slot 0
         gitcap::Slot& n = h->slots[0];
@@ -982,7 +984,7 @@ int gitcap_beam_search(gitcap_t* h, const float* frames, int B, int F, int beams
         }());
         rc = text_forward(h, h->beam.words, 1, rows, beams, t, 1, h->beam_logits, 0, nullptr, 0, nullptr, 0, s);
         if (rc) return rc;
-        HIP_OK(h, launch_beam_topk(h->beam_logits, V, h->beam.beam_scores, B, beams, V, K, h->cand_scores, h->cand_idx, s));
+        HIP_OK(h, launch_beam_topk(h->beam_logits, V, h->beam.beam_scores, B, beams, V, K, h->cand_scores, h->cand_idx, h->topk_scratch, s));
         HIP_OK(h, launch_beam_step(h->beam, h->cand_scores, h->cand_idx, B, beams, K, V, cur_len, L, h->c.sep_token_id,
                                    length_penalty, cur, s));
     }
@@ -1037,8 +1039,13 @@ int gitcap_preprocess(const uint8_t* frames_hwc_bgr, int nf, int H, int W, float
 
 int gitcap_beam_topk(const float* logits, int ld, const float* beam_scores, int B, int beams, int V, int K,
                      float* out_scores, int32_t* out_idx, void* stream) {
-    if (!logits || !beam_scores || !out_scores || !out_idx) return GITCAP_ERR_ARG;
-    hipError_t e = launch_beam_topk(logits, ld, beam_scores, B, beams, V, K, out_scores, out_idx, (hipStream_t)stream);
+    if (!logits || !beam_scores || !out_scores || !out_idx || B <= 0 || beams <= 0 || V <= 0 || K <= 0) return GITCAP_ERR_ARG;
+    // no handle here: the scratch of the two-stage top-k is a stream-ordered allocation
+    void* scratch = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMallocAsync(&scratch, beam_topk_scratch_bytes(B, beams, V, K), s) != hipSuccess) return GITCAP_ERR_NOMEM;
+    const hipError_t e = launch_beam_topk(logits, ld, beam_scores, B, beams, V, K, out_scores, out_idx, scratch, s);
+    (void)hipFreeAsync(scratch, s);
     return e == hipSuccess ? 0 : (e == hipErrorInvalidValue ? GITCAP_ERR_ARG : GITCAP_ERR_HIP);
 }
 

@@ -153,8 +153,9 @@ hipError_t launch_fill_i64(int64_t* p, int ld, int rows, int64_t v, hipStream_t 
 hipError_t launch_gather_txt_rows(const bf16_t* src, bf16_t* dst, const int32_t* src_rows, int rows,
                                   int t_len, int Tmax, int width, hipStream_t s);
 // top-K over (beam, vocab) of log_softmax(logits) + beam_scores, one block per batch element
+size_t beam_topk_scratch_bytes(int B, int beams, int V, int K);   // device scratch launch_beam_topk needs (V <= 131072)
 hipError_t launch_beam_topk(const float* logits, int ld, const float* beam_scores, int B, int beams, int V, int K,
-                            float* out_scores, int* out_idx, hipStream_t s);
+                            float* out_scores, int* out_idx, void* scratch, hipStream_t s);
 // uint8 HWC BGR frames [nf][H][W][3] -> CLIP-normalised fp32 NCHW [nf][3][crop][crop] (bicubic resize + centre crop)
 hipError_t launch_preprocess(const unsigned char* in, float* out, int nf, int H, int W, int crop, hipStream_t s);
 // the same transform fused with the patch gather: -> bf16 patch rows [nf*G*G][Kp] (layout of launch_im2col)

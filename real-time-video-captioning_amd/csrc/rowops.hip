@@ -222,53 +222,61 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restri
 }
 
 // ---- beam candidates: top-K of (log_softmax(logits[b*beams+j]) + beam_score[b*beams+j]) over j, v ----
-// One block per batch element.  Replaces log_softmax (:557) + add (:561) + view + topk (:563-565) of
-// the reference search loop (src/models/model.py); flat index = j*V + v, sorted descending, ties by
-// smaller flat index.
+// Replaces log_softmax (:557) + add (:561) + view + topk (:563-565) of the reference search loop
+// (src/models/model.py); flat index = j*V + v, sorted descending, ties by smaller flat index.
+// Two launches (a single workgroup per clip scanned beams x V = 122 K logits three times: 371 us at the configs[4] shape,
+// a quarter of its search loop):
+//   chunks: one workgroup per (row, 2048-logit chunk): chunk max, sum of exp(x - max), and the chunk's top K by value
+//           (inside a row the order by logit IS the order by score);
+//   merge:  one wave per clip: log-sum-exp of every row from the chunk statistics (fixed order), score of every candidate,
+//           top K of the beams x chunks x K candidates.  The global top K is a subset of the per-chunk top K's: exact.
+constexpr int BT_CHUNK = 2048;
+
 template <int KMAX>
-__global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict__ logits, int ld,
-                                                        const float* __restrict__ beam_scores, int beams, int V, int K,
-                                                        float* __restrict__ out_scores, int* __restrict__ out_idx) {
+__global__ __launch_bounds__(256) void beam_topk_chunks_kernel(const float* __restrict__ logits, int ld, int V, int K, int nch,
+                                                               float2* __restrict__ stats, float* __restrict__ cval,
+                                                               int* __restrict__ cidx) {
     __shared__ float red[4];
     __shared__ int redi[4];
-    __shared__ float lse[16];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int j = 0; j < beams; ++j) {                                  // log-sum-exp of every beam row
-        const float* row = logits + (size_t)(b * beams + j) * ld;
-        float m = -INFINITY;
-        for (int i = tid; i < V; i += 256) m = fmaxf(m, row[i]);
-        m = wave_max(m);
-        if (lane == 0) red[wid] = m;
-        __syncthreads();
-        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        __syncthreads();
-        float s = 0.f;
-        for (int i = tid; i < V; i += 256) s += expf(row[i] - m);
-        s = wave_sum(s);
-        if (lane == 0) red[wid] = s;
-        __syncthreads();
-        if (tid == 0) lse[j] = m + logf(red[0] + red[1] + red[2] + red[3]);
-        __syncthreads();
+    const int row = blockIdx.x / nch, c = blockIdx.x - row * nch;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float* src = logits + (size_t)row * ld;
+    float x[8];
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int i = c * BT_CHUNK + q * 256 + tid;
+        x[q] = i < V ? src[i] : -INFINITY;
+        m = fmaxf(m, x[q]);
     }
+    m = wave_max(m);
+    if (lane == 0) red[wid] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sum += x[q] == -INFINITY ? 0.f : expf(x[q] - m);      // (a chunk of -inf only: m = -inf, sum = 0)
+    sum = wave_sum(sum);
+    if (lane == 0) red[wid] = sum;
+    __syncthreads();
+    if (tid == 0) stats[blockIdx.x] = float2{m, (red[0] + red[1]) + (red[2] + red[3])};
+    __syncthreads();
     float tv[KMAX];
     int ti[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) { tv[k] = -INFINITY; ti[k] = 0x7fffffff; }
-    for (int j = 0; j < beams; ++j) {
-        const float* row = logits + (size_t)(b * beams + j) * ld;
-        const float add = beam_scores[b * beams + j] - lse[j];
-        for (int i = tid; i < V; i += 256) {
-            float v = row[i] + add;
-            int id = j * V + i;
-            if (v > tv[KMAX - 1]) {                                     // ascending ids per thread: strict > keeps the earlier one
 #pragma unroll
-                for (int k = 0; k < KMAX; ++k) {
-                    if (v > tv[k]) { const float fv = tv[k]; const int fi = ti[k]; tv[k] = v; ti[k] = id; v = fv; id = fi; }
-                }
-            }
+    for (int q = 0; q < 8; ++q) {                                        // ascending ids per thread: strict > keeps the earlier one
+        float v = x[q];
+        int id = c * BT_CHUNK + q * 256 + tid;
+        if (v > tv[KMAX - 1]) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (v > tv[k]) { const float fv = tv[k]; const int fi = ti[k]; tv[k] = v; ti[k] = id; v = fv; id = fi; }
         }
     }
-    for (int k = 0; k < K; ++k) {                                      // K rounds of block arg-max over the list heads
+    for (int k = 0; k < K; ++k) {                                        // K rounds of block arg-max over the list heads
         float bv = tv[0];
         int bi = ti[0];
 #pragma unroll
@@ -282,13 +290,61 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict_
         bv = red[0]; bi = redi[0];
         for (int w = 1; w < 4; ++w)
             if (red[w] > bv || (red[w] == bv && redi[w] < bi)) { bv = red[w]; bi = redi[w]; }
-        if (tid == 0) { out_scores[b * K + k] = bv; out_idx[b * K + k] = bi; }
-        if (ti[0] == bi) {                                               // the owner pops its head
+        if (tid == 0) { cval[(size_t)blockIdx.x * K + k] = bv; cidx[(size_t)blockIdx.x * K + k] = bi; }
+        if (ti[0] == bi && bi != 0x7fffffff) {                           // the owner pops its head
 #pragma unroll
             for (int q = 0; q + 1 < KMAX; ++q) { tv[q] = tv[q + 1]; ti[q] = ti[q + 1]; }
             tv[KMAX - 1] = -INFINITY; ti[KMAX - 1] = 0x7fffffff;
         }
         __syncthreads();
+    }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(64) void beam_topk_merge_kernel(const float2* __restrict__ stats, const float* __restrict__ cval,
+                                                             const int* __restrict__ cidx, const float* __restrict__ beam_scores,
+                                                             int beams, int V, int K, int nch, float* __restrict__ out_scores,
+                                                             int* __restrict__ out_idx) {
+    __shared__ float add[16];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int j = 0; j < beams; ++j) {                                    // log-sum-exp of row j from its chunks (nch <= 64)
+        const float2 st = lane < nch ? stats[(size_t)(b * beams + j) * nch + lane] : float2{-INFINITY, 0.f};
+        const float M = wave_max(st.x);
+        const float S = wave_sum(st.y == 0.f ? 0.f : st.y * expf(st.x - M));
+        if (lane == 0) add[j] = beam_scores[b * beams + j] - (M + logf(S));
+    }
+    __syncthreads();
+    float tv[KMAX];
+    int ti[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) { tv[k] = -INFINITY; ti[k] = 0x7fffffff; }
+    const int per_row = nch * K, total = beams * per_row;
+    for (int t = lane; t < total; t += 64) {
+        const int j = t / per_row;
+        const size_t at = (size_t)(b * beams) * per_row + t;
+        const int ci = cidx[at];
+        if (ci == 0x7fffffff) continue;                                  // an empty slot of a short last chunk
+        float v = cval[at] + add[j];
+        int id = j * V + ci;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (v > tv[k] || (v == tv[k] && id < ti[k])) { const float fv = tv[k]; const int fi = ti[k]; tv[k] = v; ti[k] = id; v = fv; id = fi; }
+    }
+    for (int k = 0; k < K; ++k) {                                        // K rounds of wave arg-max over the list heads
+        float bv = tv[0];
+        int bi = ti[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float v2 = __shfl_xor(bv, o);
+            const int i2 = __shfl_xor(bi, o);
+            if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+        }
+        if (lane == 0) { out_scores[b * K + k] = bv; out_idx[b * K + k] = bi; }
+        if (ti[0] == bi && bi != 0x7fffffff) {
+#pragma unroll
+            for (int q = 0; q + 1 < KMAX; ++q) { tv[q] = tv[q + 1]; ti[q] = ti[q + 1]; }
+            tv[KMAX - 1] = -INFINITY; ti[KMAX - 1] = 0x7fffffff;
+        }
     }
 }
 
@@ -474,11 +530,26 @@ hipError_t launch_argmax_final(const float* amax_val, const int* amax_idx, int n
     return hipGetLastError();
 }
 
+size_t beam_topk_scratch_bytes(int B, int beams, int V, int K) {
+    const size_t n = (size_t)B * beams * ((V + BT_CHUNK - 1) / BT_CHUNK);
+    return n * 8 + n * K * 8;                          // chunk (max, sum) + K (value, index) candidates per chunk
+}
+
 hipError_t launch_beam_topk(const float* logits, int ld, const float* beam_scores, int B, int beams, int V, int K,
-                            float* out_scores, int* out_idx, hipStream_t s) {
-    if (B <= 0 || beams <= 0 || beams > 16 || K <= 0 || K > 16 || K > beams * V) return hipErrorInvalidValue;
-    if (K <= 8) hipLaunchKernelGGL(beam_topk_kernel<8>, dim3(B), dim3(256), 0, s, logits, ld, beam_scores, beams, V, K, out_scores, out_idx);
-    else hipLaunchKernelGGL(beam_topk_kernel<16>, dim3(B), dim3(256), 0, s, logits, ld, beam_scores, beams, V, K, out_scores, out_idx);
+                            float* out_scores, int* out_idx, void* scratch, hipStream_t s) {
+    const int nch = (V + BT_CHUNK - 1) / BT_CHUNK;
+    if (B <= 0 || beams <= 0 || beams > 16 || K <= 0 || K > 16 || K > beams * V || nch > 64 || !scratch) return hipErrorInvalidValue;
+    const size_t n = (size_t)B * beams * nch;
+    float2* stats = (float2*)scratch;
+    float* cval = (float*)(stats + n);
+    int* cidx = (int*)(cval + n * K);
+    if (K <= 8) {
+        hipLaunchKernelGGL(beam_topk_chunks_kernel<8>, dim3((unsigned)n), dim3(256), 0, s, logits, ld, V, K, nch, stats, cval, cidx);
+        hipLaunchKernelGGL(beam_topk_merge_kernel<8>, dim3(B), dim3(64), 0, s, stats, cval, cidx, beam_scores, beams, V, K, nch, out_scores, out_idx);
+    } else {
+        hipLaunchKernelGGL(beam_topk_chunks_kernel<16>, dim3((unsigned)n), dim3(256), 0, s, logits, ld, V, K, nch, stats, cval, cidx);
+        hipLaunchKernelGGL(beam_topk_merge_kernel<16>, dim3(B), dim3(64), 0, s, stats, cval, cidx, beam_scores, beams, V, K, nch, out_scores, out_idx);
+    }
     return hipGetLastError();
 }
 
