@@ -972,16 +972,11 @@ int gitcap_beam_search(gitcap_t* h, const float* frames, int B, int F, int beams
     // position cur_len are ranked, bookkept and the text K/V rows follow their beams -- no host round trip
     for (int cur_len = 1, cur = 0; cur_len < L; ++cur_len, cur ^= 1) {
         const int t = cur_len - 1;
-        if (t > 0) HIP_OK(h, [&]() -> hipError_t {                          // rows continue beam src_rows[r]
-            const size_t layer = (size_t)h->R * h->Tmax * 3 * h->D;
-            for (int l = 0; l < h->c.dec_layers; ++l) {
-                hipError_t e = launch_gather_txt_rows(h->kv_txt + l * layer, h->kv_txt2 + l * layer, h->beam.src_rows, rows, t,
-                                                      h->Tmax, 3 * h->D, s);
-                if (e != hipSuccess) return e;
-            }
+        if (t > 0) {                                                         // rows continue beam src_rows[r]: all layers, one launch
+            HIP_OK(h, launch_gather_txt_rows(h->kv_txt, h->kv_txt2, h->beam.src_rows, rows, t, h->Tmax, 3 * h->D, h->c.dec_layers,
+                                             (size_t)h->R * h->Tmax * 3 * h->D, s));
             std::swap(h->kv_txt, h->kv_txt2);
-            return hipSuccess;
-        }());
+        }
         rc = text_forward(h, h->beam.words, 1, rows, beams, t, 1, h->beam_logits, 0, nullptr, 0, nullptr, 0, s);
         if (rc) return rc;
         HIP_OK(h, launch_beam_topk(h->beam_logits, V, h->beam.beam_scores, B, beams, V, K, h->cand_scores, h->cand_idx, h->topk_scratch, s));
@@ -999,9 +994,8 @@ int gitcap_reorder_rows(gitcap_t* h, const int32_t* src_rows, int rows, int t_le
         return fail(h, GITCAP_ERR_ARG, "reorder_rows: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     HIP_OK(h, join_async(h, s));
-    const size_t layer = (size_t)h->R * h->Tmax * 3 * h->D;
-    for (int l = 0; l < h->c.dec_layers; ++l)
-        HIP_OK(h, launch_gather_txt_rows(h->kv_txt + l * layer, h->kv_txt2 + l * layer, src_rows, rows, t_len, h->Tmax, 3 * h->D, s));
+    HIP_OK(h, launch_gather_txt_rows(h->kv_txt, h->kv_txt2, src_rows, rows, t_len, h->Tmax, 3 * h->D, h->c.dec_layers,
+                                     (size_t)h->R * h->Tmax * 3 * h->D, s));
     std::swap(h->kv_txt, h->kv_txt2);
     return 0;
 }

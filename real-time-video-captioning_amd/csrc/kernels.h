@@ -151,7 +151,7 @@ hipError_t launch_argmax(const float* logits, int ld, int rows, int V, int64_t* 
 hipError_t launch_finish_steps(const int32_t* sep_cnt, int rows, int max_len, int stop, int32_t* steps_out, hipStream_t s);
 hipError_t launch_fill_i64(int64_t* p, int ld, int rows, int64_t v, hipStream_t s);
 hipError_t launch_gather_txt_rows(const bf16_t* src, bf16_t* dst, const int32_t* src_rows, int rows,
-                                  int t_len, int Tmax, int width, hipStream_t s);
+                                  int t_len, int Tmax, int width, int layers, size_t layer_stride, hipStream_t s);
 // top-K over (beam, vocab) of log_softmax(logits) + beam_scores, one block per batch element
 size_t beam_topk_scratch_bytes(int B, int beams, int V, int K);   // device scratch launch_beam_topk needs (V <= 131072)
 hipError_t launch_beam_topk(const float* logits, int ld, const float* beam_scores, int B, int beams, int V, int K,

@@ -482,13 +482,14 @@ __global__ void fill_i64_kernel(int64_t* p, int ld, int rows, int64_t v) {
     if (r < rows) p[(size_t)r * ld] = v;
 }
 
-// dst[r][t][:] = src[src_rows[r]][t][:] for t < t_len (text K/V rows, `width` bf16 per position)
+// dst[l][r][t][:] = src[l][src_rows[r]][t][:] for t < t_len, every layer l = blockIdx.y in one launch
+// (text K/V rows, `width` bf16 per position, `layer_stride` elements between layers)
 __global__ void gather_txt_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
-                                       const int32_t* __restrict__ src_rows, int t_len, int Tmax, int width) {
+                                       const int32_t* __restrict__ src_rows, int t_len, int Tmax, int width, size_t layer_stride) {
     const int r = blockIdx.x, sr = src_rows[r];
     const int n8 = t_len * width / 8;
-    const uint4* s = (const uint4*)(src + (size_t)sr * Tmax * width);
-    uint4* d = (uint4*)(dst + (size_t)r * Tmax * width);
+    const uint4* s = (const uint4*)(src + blockIdx.y * layer_stride + (size_t)sr * Tmax * width);
+    uint4* d = (uint4*)(dst + blockIdx.y * layer_stride + (size_t)r * Tmax * width);
     for (int i = threadIdx.x; i < n8; i += blockDim.x) d[i] = s[i];
 }
 
@@ -645,7 +646,8 @@ hipError_t launch_fill_i64(int64_t* p, int ld, int rows, int64_t v, hipStream_t 
 }
 
 hipError_t launch_gather_txt_rows(const bf16_t* src, bf16_t* dst, const int32_t* src_rows, int rows,
-                                  int t_len, int Tmax, int width, hipStream_t s) {
-    hipLaunchKernelGGL(gather_txt_rows_kernel, dim3(rows), dim3(256), 0, s, src, dst, src_rows, t_len, Tmax, width);
+                                  int t_len, int Tmax, int width, int layers, size_t layer_stride, hipStream_t s) {
+    if (rows <= 0 || layers <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_txt_rows_kernel, dim3(rows, layers), dim3(256), 0, s, src, dst, src_rows, t_len, Tmax, width, layer_stride);
     return hipGetLastError();
 }
