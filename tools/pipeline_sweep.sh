@@ -1,0 +1,9 @@
+run() { echo "== $*"; env "$@" timeout -k 10 200 python bench.py --plain --no-cpu-baseline $ARGS 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['p50_latency_ms'])" || exit 1; }
+ARGS="" run X=1
+ARGS="--inflight 2" run X=1
+ARGS="--inflight 4" run X=1
+ARGS="" run GITCAP_TXT_STREAMS=1
+ARGS="" run GITCAP_TXT_STREAMS=3
+ARGS="--inflight 4" run GITCAP_TXT_STREAMS=3
+ARGS="--inflight 4" run GITCAP_TXT_STREAMS=4
+ARGS="" run X=1
