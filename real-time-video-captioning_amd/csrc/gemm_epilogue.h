@@ -185,7 +185,7 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
         unsigned spins = 0;
         while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen) {
             __builtin_amdgcn_s_sleep(12);                   // ~0.3 us between polls: 200 spinning tiles must not load the fabric
-            if (++spins > (1u << 22)) __builtin_trap();
+            if (++spins > (1u << 26)) __builtin_trap();     // ~30 s: far beyond any preemption of a sibling; a lost arrival is loud
         }
     }
     __syncthreads();
