@@ -145,6 +145,28 @@ def test_full_size_properties(captioner_cls, B, F):
     _tokens_match_margin_gated(a[5:6].cpu(), emul, fr[5:6].cpu())
 
 
+@pytest.mark.parametrize("size", ["tiny", "base"])
+@pytest.mark.parametrize("B", [1, 2])
+def test_one_and_two_row_steps_equal_teacher_forced(captioner_cls, size, B):
+    """With one or two text rows the q|k|v launch computes its own input rows (row prologue, csrc/skinny.hip) instead of
+    reading what the row kernels wrote; a teacher-forced pass over the same tokens has B*T > 2 rows and uses the row
+    kernels.  Same inline code on both paths: every cached step's logits must equal the teacher-forced logits BITWISE,
+    and a clip decoded alone (prologue) must give the ids it gets inside a batch of 5 (row kernels)."""
+    cfg = git_tiny(2) if size == "tiny" else git_base(2)
+    w = synthetic_weights(cfg, 3)
+    m = captioner_cls(cfg, w, max_batch=5, max_frames=2, max_text_len=12)
+    fr = make_frames(5, 2, cfg.image_size, 17).cuda()
+    full = m.greedy_decode(fr, max_len=12, stop="never")
+    ids = m.greedy_decode(fr[:B], max_len=12, stop="never")
+    assert torch.equal(ids, full[:B])
+    _, vis = m.forward_image_enc(fr[:B])
+    tf = m.forward_decoder(ids[:, :-1], vis)                       # [B, 12, V], row kernels (B*12 rows)
+    assert torch.equal(tf.argmax(-1), ids[:, 1:])
+    for t in range(12):                                             # cached single steps, in order (step t writes the K/V of position t)
+        step = m.step_logits(ids[:, t], t)
+        assert torch.equal(step, tf[:, t]), t
+
+
 def test_stop_rule_and_row_semantics(captioner_cls):
     """model.py:184: stop only when ALL rows emit SEP in the same step."""
     cfg = git_tiny(2)
