@@ -218,6 +218,10 @@ int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float
 int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const float* resid, const float* gamma,
                        const float* beta, float eps, float* out_f32, void* out_bf16, int M, int N, int K, int post,
                        int fused, int tile, void* stream);
+/* Speed-only switches at run time (what the GITCAP_* environment variables set once per process; INTEGRATION.md par. 9), so that
+ * one process can check that results do not depend on them.  key 0: GEMM + LayerNorm epilogue on/off; 1: one/two-row prologue
+ * on/off; 2: 256x256-tile threshold; 3: 128x128-tile threshold.  Returns the previous value (< 0: bad key).  Not thread safe. */
+int gitcap_dbg_config(int key, int value);
 /* attn_full: qkv [G*S][3*H*64] bf16 -> ctx [G*S][H*64] bf16 */
 int gitcap_dbg_attn_full(const void* qkv, void* ctx, int G, int S, int H, void* stream);
 /* layernorm: x fp32 [rows][D] -> out_f32 / out_bf16 (either may be NULL) */

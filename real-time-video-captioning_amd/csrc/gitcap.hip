@@ -19,6 +19,9 @@
 #define GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, s) ((tile) == 256 ? launch_gemm256(a, epi, s) : (tile) == 64 ? launch_gemm64(a, epi, s) : launch_gemm(a, epi, s))
 #endif
 
+// shared with student.hip; gitcap_dbg_config can flip it
+bool g_row_prologue = getenv("GITCAP_NO_ROW_PROLOGUE") == nullptr;
+
 namespace {
 
 // a GEMM weight [Npad16][K]: bf16, or OCP e4m3 bytes + one power-of-two scale per row (scale != nullptr)
@@ -131,9 +134,9 @@ std::string g_create_err;
 // another one to keep up with the image pass.
 const int g_txt_streams = getenv("GITCAP_TXT_STREAMS") ? std::max(1, std::min(4, atoi(getenv("GITCAP_TXT_STREAMS")))) : 2;
 // 256x256-tile count below which the 128x128 kernel is used (GITCAP_GEMM_SMALL_TILES=0 disables the switch)
-const int g_small_tiles = getenv("GITCAP_GEMM_SMALL_TILES") ? atoi(getenv("GITCAP_GEMM_SMALL_TILES")) : 128;
+int g_small_tiles = getenv("GITCAP_GEMM_SMALL_TILES") ? atoi(getenv("GITCAP_GEMM_SMALL_TILES")) : 128;
 // 128x128-tile count below which the 64x64 kernel is used (GITCAP_GEMM_TINY_TILES=0 disables the switch)
-const int g_tiny_tiles = getenv("GITCAP_GEMM_TINY_TILES") ? atoi(getenv("GITCAP_GEMM_TINY_TILES")) : 200;     // measured crossover (tools/gemm_tiles_small.py): 180 -> 64x64, 228 -> 128x128
+int g_tiny_tiles = getenv("GITCAP_GEMM_TINY_TILES") ? atoi(getenv("GITCAP_GEMM_TINY_TILES")) : 200;     // measured crossover (tools/gemm_tiles_small.py): 180 -> 64x64, 228 -> 128x128
 
 // Tile kernel selection.  Few 256x256 tiles (small batches: one 6-frame clip is 5 x 3..12 tiles for 256 CUs) leave
 // most of the chip idle: below g_small_tiles tiles the 128x128 kernel (4x the workgroups, two per CU) is used
@@ -314,7 +317,7 @@ int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef
 // Large launches run both inside the 256x256 kernel (EPI_RESID_LN_*: the tiles of a row block exchange segment
 // statistics); small ones the 128x128 kernel + the row kernel.  Both give the same bits (ln_canon.h).
 // GITCAP_NO_GEMM_LN=1 (diagnosis / A-B only) keeps every LayerNorm a launch of its own.
-const bool g_fuse_ln = getenv("GITCAP_NO_GEMM_LN") == nullptr;
+bool g_fuse_ln = getenv("GITCAP_NO_GEMM_LN") == nullptr;
 
 int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const WRef& W, const float* bias, int M, int N,
             int K, float* xout, const float* resid, const float* ln_g, const float* ln_b, float eps, int rows,
@@ -425,8 +428,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     // partial slabs.  With one or two rows (a single clip: the webcam case) the first of the five runs inside the second
     // (skinny.hip "row prologue": every workgroup of the q|k|v launch computes the rows itself): 4 launches per layer.
     // The residual rows then alternate between two buffers (workgroup 0 writes them while the others still read the old).
-    static const bool no_rows_pro = getenv("GITCAP_NO_ROW_PROLOGUE") != nullptr;
-    const bool rows_pro = !no_rows_pro && !hid && skinny_row_prologue_ok(M, D, h->dec[0].qkvw.scale != nullptr);
+    const bool rows_pro = g_row_prologue && !hid && skinny_row_prologue_ok(M, D, h->dec[0].qkvw.scale != nullptr);
     float *xcur = h->xs, *xalt = h->xs2;
     for (int l = 0; l < c.dec_layers; ++l) {
         const DecLayer& L = h->dec[l];
@@ -1087,6 +1089,21 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
     if (!gemm256_ln_ok(a) || (!post && !resid)) return GITCAP_ERR_ARG;
     const hipError_t e = launch_gemm256(a, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s);
     return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
+}
+
+// Speed-only switches at run time (the same ones the GITCAP_* environment variables set once per process): lets ONE process
+// check that results do not depend on them.  key 0: GEMM + LayerNorm epilogue on/off, 1: one/two-row prologue on/off,
+// 2: 256-tile threshold (GITCAP_GEMM_SMALL_TILES), 3: 128-tile threshold (GITCAP_GEMM_TINY_TILES).  Returns the old value.
+int gitcap_dbg_config(int key, int value) {
+    int old = -1;
+    switch (key) {
+        case 0: old = g_fuse_ln; g_fuse_ln = value != 0; break;
+        case 1: old = g_row_prologue; g_row_prologue = value != 0; break;
+        case 2: old = g_small_tiles; g_small_tiles = value; break;
+        case 3: old = g_tiny_tiles; g_tiny_tiles = value; break;
+        default: return GITCAP_ERR_ARG;
+    }
+    return old;
 }
 
 int gitcap_dbg_attn_full(const void* qkv, void* ctx, int G, int S, int H, void* stream) {

@@ -61,6 +61,7 @@ struct SkinnyArgs {
         float* xf;                         // [M][K]
     } ln;
 };
+extern bool g_row_prologue;                                 // gitcap.hip: GITCAP_NO_ROW_PROLOGUE / gitcap_dbg_config(1, .)
 bool skinny_row_prologue_ok(int M, int K, bool fp8);         // shapes the row-prologue form is instantiated for
 hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s);
 bool skinny_full_ok(int K);                                  // K depths launch_skinny is instantiated for

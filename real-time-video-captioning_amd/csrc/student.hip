@@ -115,11 +115,11 @@ struct gitcap_student {
     int* amax_idx = nullptr;
     bf16_t *xb = nullptr, *qc = nullptr, *ctx = nullptr, *ffn = nullptr, *kvs = nullptr, *memb = nullptr, *memkv = nullptr;
     int32_t* sep_cnt = nullptr;
-    // greedy loop captured as a hipGraph (one per (B, max_len, stop)); it works on the handle's own
+    // greedy loop captured as a hipGraph (one per (B, max_len, stop, row-prologue switch)); it works on the handle's own
     // ids / steps buffers, which are copied to the caller's after the replay
     int64_t* g_ids = nullptr;
     int32_t* g_steps = nullptr;
-    struct GreedyGraph { int B, max_len, stop; hipGraphExec_t exec; };
+    struct GreedyGraph { int B, max_len, stop; bool rows_pro; hipGraphExec_t exec; };
     std::vector<GreedyGraph> graphs;
     hipStream_t cap_stream = nullptr;   // capture only (the legacy default stream cannot be captured); replays run on the caller's stream
     // resolved weights
@@ -210,8 +210,7 @@ int text_forward(gitcap_student* h, const int64_t* ids, int ld_ids, int rows, in
     // Each post-LN sub-layer is split-K partial slabs -> sum + bias + residual + LayerNorm.  With one or two rows (the webcam
     // case) that row kernel is not launched: the projection that consumes its output computes the rows itself (skinny.hip
     // "row prologue", same code -> same bits) and workgroup 0 writes the fp32 residual rows to the other of two buffers.
-    static const bool no_rows_pro = getenv("GITCAP_NO_ROW_PROLOGUE") != nullptr;
-    const bool rows_pro = !no_rows_pro && skinny_row_prologue_ok(M, D, false);
+    const bool rows_pro = g_row_prologue && skinny_row_prologue_ok(M, D, false);
     float *xcur = h->xf, *xalt = h->xf2;
     struct { bool on; const float *bias, *g, *b; int nslab; } pend{false, nullptr, nullptr, nullptr, 0};
     // out = epi(LN-output . W^T + bias): the LN output is xb, or -- when a reduce + LayerNorm is pending -- computed in place
@@ -454,7 +453,7 @@ int gitcap_student_greedy(gitcap_student_t* h, const float* memory, int B, int m
     if (use_graph) {
         hipGraphExec_t exec = nullptr;
         for (auto& g : h->graphs)
-            if (g.B == B && g.max_len == max_len && g.stop == stop) exec = g.exec;
+            if (g.B == B && g.max_len == max_len && g.stop == stop && g.rows_pro == g_row_prologue) exec = g.exec;
         if (!exec) {
             hipGraph_t graph = nullptr;
             if (!h->cap_stream) S_HIP_OK(h, hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
@@ -466,7 +465,7 @@ int gitcap_student_greedy(gitcap_student_t* h, const float* memory, int B, int m
             e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             S_HIP_OK(h, e);
-            h->graphs.push_back({B, max_len, stop, exec});
+            h->graphs.push_back({B, max_len, stop, g_row_prologue, exec});
         }
         S_HIP_OK(h, hipGraphLaunch(exec, s));
     } else if ((rc = enqueue_loop(s))) {

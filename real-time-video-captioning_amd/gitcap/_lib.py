@@ -43,6 +43,7 @@ SYMBOLS = {
     "gitcap_dbg_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gitcap_dbg_gemm_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gitcap_dbg_config": (c_int, [c_int, c_int]),
     "gitcap_dbg_attn_full": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gitcap_dbg_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gitcap_workspace_bytes": (c_int, [c_void_p, POINTER(c_int64)]),

@@ -167,6 +167,37 @@ def test_one_and_two_row_steps_equal_teacher_forced(captioner_cls, size, B):
         assert torch.equal(step, tf[:, t]), t
 
 
+def test_results_do_not_depend_on_speed_switches(captioner_cls):
+    """Tile choice (256 / 128 / 64), the GEMM + LayerNorm epilogue and the one/two-row prologue are speed decisions taken from
+    the batch size: flipping each of them at run time (gitcap_dbg_config) must not change a bit of the visual features, the
+    teacher-forced logits or the captions -- at GIT-base size, for a batch of 8 clips (256-tile kernels) and a single clip."""
+    from gitcap import _lib
+    lib = _lib.load()
+    cfg = git_base(6)
+    w = synthetic_weights(cfg, 0)
+    m = captioner_cls(cfg, w, max_batch=8, max_frames=6, max_text_len=12)
+    fr = make_frames(8, 6, cfg.image_size, 23).cuda()
+
+    def run(n):
+        _, vis = m.forward_image_enc(fr[:n])
+        ids = m.greedy_decode(fr[:n], max_len=12, stop="never")
+        return vis.clone(), ids.clone(), m.forward_decoder(ids[:, :-1], vis).clone()
+    base8, base1 = run(8), run(1)
+    assert torch.equal(base1[1], base8[1][:1]) and torch.equal(base1[0], base8[0][:1])
+    settings = [(0, 0), (1, 0), (2, 1 << 30), (3, 0), (3, 1 << 30), (2, 1)]   # (key, value); (2, 1): 256-tile kernels even for one clip
+    for key, value in settings:
+        old = lib.gitcap_dbg_config(key, value)
+        assert old >= 0
+        try:
+            for base, n in ((base8, 8), (base1, 1)):
+                got = run(n)
+                for a, b in zip(base, got):
+                    assert torch.equal(a, b), (key, value, n)
+        finally:
+            lib.gitcap_dbg_config(key, old)
+    assert lib.gitcap_dbg_config(99, 0) < 0
+
+
 def test_stop_rule_and_row_semantics(captioner_cls):
     """model.py:184: stop only when ALL rows emit SEP in the same step."""
     cfg = git_tiny(2)

@@ -256,3 +256,25 @@ def test_gpu_student_batch_invariance_and_determinism():
     # a permutation of the batch permutes the result
     perm = torch.tensor([3, 0, 4, 1, 2])
     assert torch.equal(m.greedy_decode(mem[perm], max_len=25, stop="never"), ids[perm])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "base"])
+def test_gpu_student_row_prologue_switch_changes_nothing(name):
+    """With one or two rows the row LayerNorms run inside the consuming projection (csrc/skinny.hip "row prologue"): switching
+    that off at run time (the hipGraph is re-captured) must give the same ids bit for bit, alone and as the first rows of a
+    batch of 4 (which never uses the prologue)."""
+    from gitcap import _lib
+    lib = _lib.load()
+    cfg = student_tiny() if name == "tiny" else student_base()
+    m = _student(cfg, student_synthetic_weights(cfg, 0), max_batch=4, max_text_len=16)
+    mem = make_memory(4, cfg.mem_tokens, cfg.d_model, 9).cuda()
+    full = m.greedy_decode(mem, max_len=16, stop="never")
+    on = [m.greedy_decode(mem[:n], max_len=16, stop="never").clone() for n in (1, 2)]
+    old = lib.gitcap_dbg_config(1, 0)
+    try:
+        off = [m.greedy_decode(mem[:n], max_len=16, stop="never").clone() for n in (1, 2)]
+    finally:
+        lib.gitcap_dbg_config(1, old)
+    for a, b, n in zip(on, off, (1, 2)):
+        assert torch.equal(a, b) and torch.equal(a, full[:n])
