@@ -151,7 +151,7 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
             const int m = mw + ml, n = nb + rc * 4;
             f32x4 v = *(const f32x4*)(ep + ml * RS + rc * 16);
             if (a.resid) v += *(const f32x4*)(a.resid + (size_t)m * a.ldr + n);
-            if (!POST) *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;      // x itself: the residual stream
+            if (!POST && a.out) *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;      // x itself: the residual stream
             xr[x][it] = v;
             const float2 st = ln_seg_stats(v);
             if (rc == 0) st_lds[(wm * 64 + ml) * 4 + wn * 2 + x] = st;
@@ -217,8 +217,10 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
         for (int it = 0; it < 16; ++it) {
             const int ml = it * 4 + rr;
             const float2 mr = row_lds[ml];
-            const f32x4 y = ln_apply(xr[x][it], mr.x, mr.y, g4, b4);
+            f32x4 y = ln_apply(xr[x][it], mr.x, mr.y, g4, b4);
             const size_t m = (size_t)(mw + ml);
+            if (!POST && a.ln_add) y += *(const f32x4*)(a.ln_add + (size_t)(((mw + ml) / a.ln_add_div) % a.ln_add_mod) * a.N + n);
+            if (!POST && a.ln_out_f32 && mw + ml < a.valid_rows) *(f32x4*)(a.ln_out_f32 + m * a.ld_ln_f32 + n) = y;
             if (POST) *(f32x4*)((float*)a.out + m * a.ldo + n) = y;
             uint2 o;
             o.x = pack_bf2(y[0], y[1]);

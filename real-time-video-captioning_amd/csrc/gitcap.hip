@@ -281,7 +281,7 @@ int ws_alloc(gitcap* h, T** p, size_t count) {
 int ln(gitcap* h, hipStream_t s, const float* x, int ldx, const float* g, const float* b, float eps, int rows, int D,
        float* of, int ldf, bf16_t* ob, int ldb, const float* addv = nullptr, int add_div = 1, int add_mod = 1) {
     ProfScope ps(h, GITCAP_PROF_ROWOPS, s, 0.0, (double)rows * D * (4.0 + (of ? 4.0 : 0.0) + (ob ? 2.0 : 0.0)));
-    LnArgs a{x, ldx, g, b, eps, rows, D, of, ldf, ob, ldb, addv, add_div, add_mod};
+    LnArgs a{x, ldx, g, b, eps, rows, D, of, ldf, ob, ldb, addv, add_div, add_mod, nullptr, nullptr, 0.f};
     HIP_OK(h, launch_layernorm(a, s));
     return 0;
 }
@@ -321,26 +321,28 @@ bool g_fuse_ln = getenv("GITCAP_NO_GEMM_LN") == nullptr;
 
 int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const WRef& W, const float* bias, int M, int N,
             int K, float* xout, const float* resid, const float* ln_g, const float* ln_b, float eps, int rows,
-            bf16_t* ln_out, float* scratch) {
+            bf16_t* ln_out, float* scratch, const float* addv = nullptr, int add_div = 1, int add_mod = 1, float* ln_f32 = nullptr) {
     hipError_t e;
     GemmArgs a{};
     a.A = A; a.lda = lda; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = xout; a.ldo = N; a.resid = resid; a.ldr = N;
     a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = eps; a.ln_out = ln_out; a.ld_ln = N; a.ln_stats = h->ln_stats; a.ln_cnt = h->ln_cnt;
+    a.ln_add = addv; a.ln_add_div = add_div; a.ln_add_mod = add_mod; a.ln_out_f32 = ln_f32; a.ld_ln_f32 = N; a.valid_rows = rows;
     // ln_out may be the A operand itself (visual projection): a tile writes its rows only after every tile that reads
     // them has finished its K loop (that is what the exchange waits for) -- as long as both views have the same row stride
     const bool alias_ok = (const void*)A != (const void*)ln_out || lda == N;
-    if (g_fuse_ln && alias_ok && gemm256_ln_ok(a) && (M >> 8) * (N >> 8) >= g_small_tiles && (post || resid)) {
+    if (g_fuse_ln && alias_ok && gemm256_ln_ok(a) && (M >> 8) * (N >> 8) >= g_small_tiles && (post ? (xout && !addv && !ln_f32) : resid != nullptr)) {
         a.W = stage_weight(h, s, W, N, K, &e);
         HIP_OK(h, e);
         const double R = h->prof_rows;      // A + W + fp32 out + bf16 LayerNorm out (+ fp32 residual read)
-        ProfScope ps(h, GITCAP_PROF_GEMM_LN, s, 2.0 * R * N * K, 2.0 * R * K + 2.0 * N * K + R * N * (6.0 + (resid ? 4.0 : 0.0)));
+        ProfScope ps(h, GITCAP_PROF_GEMM_LN, s, 2.0 * R * N * K, 2.0 * R * K + 2.0 * N * K + R * N * ((xout ? 4.0 : 0.0) + 2.0 + (ln_f32 ? 4.0 : 0.0) + (resid ? 4.0 : 0.0)));
         HIP_OK(h, launch_gemm256(a, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s));
         return 0;
     }
     int rc;
-    float* xo = post ? scratch : xout;
+    // GEMM, then the row kernel: x goes to the scratch (post), to xout, or -- when the caller does not want it -- over the residual
+    float* xo = post ? scratch : (xout ? xout : const_cast<float*>(resid));
     if ((rc = gemm(h, s, resid ? EPI_BIAS_RESID_F32 : EPI_BIAS_F32, A, lda, W, bias, M, N, K, xo, N, resid, N))) return rc;
-    return ln(h, s, xo, N, ln_g, ln_b, eps, rows, N, post ? xout : nullptr, N, ln_out, N);
+    return ln(h, s, xo, N, ln_g, ln_b, eps, rows, N, post ? xout : ln_f32, N, ln_out, N, addv, add_div, add_mod);
 }
 
 int skinny(gitcap* h, hipStream_t s, int epi, const bf16_t* X, int ldx, const WRef& W, const float* bias, int M,
@@ -807,11 +809,23 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
     }
     HIP_OK(h, launch_cls_rows(h->x, h->cls, h->pos, nf, N, Dv, s));
     h->prof_rows = rows;
-    if ((rc = ln(h, s, h->x, Dv, h->ln_pre_w, h->ln_pre_b, c.enc_ln_eps, rows, Dv, h->x, Dv, nullptr, 0))) return rc;
+    // ln_pre (fp32, in place: the residual stream) and the first block's LN1 (bf16: the first q|k|v operand) in one pass
+    {
+        const bool canon = Dv == 64 || Dv == 128 || Dv == 256 || Dv == 512 || Dv == 768 || Dv == 1024;
+        if (canon) {
+            ProfScope ps(h, GITCAP_PROF_ROWOPS, s, 0.0, (double)rows * Dv * 10.0);
+            LnArgs a{h->x, Dv, h->ln_pre_w, h->ln_pre_b, c.enc_ln_eps, rows, Dv, h->x, Dv, h->hb, Dv, nullptr, 1, 1,
+                     h->enc[0].ln1w, h->enc[0].ln1b, c.enc_ln_eps};
+            HIP_OK(h, launch_layernorm(a, s));
+        } else {
+            if ((rc = ln(h, s, h->x, Dv, h->ln_pre_w, h->ln_pre_b, c.enc_ln_eps, rows, Dv, h->x, Dv, nullptr, 0))) return rc;
+            if ((rc = ln(h, s, h->x, Dv, h->enc[0].ln1w, h->enc[0].ln1b, c.enc_ln_eps, rows, Dv, nullptr, 0, h->hb, Dv))) return rc;
+        }
+    }
 
     // pre-LN blocks: x += proj(attn(LN1 x)); x += fc2(qgelu(fc1(LN2 x))).  Each residual GEMM also produces the
-    // LayerNorm its consumer needs (LN2 of this block / LN1 of the next), so only the first LN1 is a launch of its own.
-    if ((rc = ln(h, s, h->x, Dv, h->enc[0].ln1w, h->enc[0].ln1b, c.enc_ln_eps, rows, Dv, nullptr, 0, h->hb, Dv))) return rc;
+    // LayerNorm its consumer needs (LN2 of this block / LN1 of the next; the last one ln_post + temporal embedding); the first
+    // LN1 came out of the ln_pre pass above.
     for (int i = 0; i < c.enc_layers; ++i) {
         const EncLayer& L = h->enc[i];
         if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, Dv, L.qkvw, L.qkvb, Mp, 3 * Dv, Dv, h->qkv, 3 * Dv))) return rc;
@@ -827,15 +841,15 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
             if ((rc = gemm_ln(h, s, false, h->ffn, c.enc_ffn, L.fc2w, L.fc2b, Mp, Dv, c.enc_ffn, h->x, h->x, Nx.ln1w, Nx.ln1b,
                               c.enc_ln_eps, rows, h->hb, nullptr))) return rc;
         } else {
-            if ((rc = gemm(h, s, EPI_BIAS_RESID_F32, h->ffn, c.enc_ffn, L.fc2w, L.fc2b, Mp, Dv, c.enc_ffn, h->x, Dv, h->x, Dv))) return rc;
+            // the last block's FC2 is followed by ln_post (+ per-frame temporal embedding, model.py:380); frames of a clip are
+            // already adjacent rows, so the concat along tokens (model.py:382) is the identity on this layout.  x itself is
+            // not needed any more.  The fp32 visual features (58 MB at B=16, F=6) are written straight into the caller's
+            // buffer and only when asked for; the decoder consumes the bf16 copy.
+            const float* addv = c.num_frames > 0 ? h->temporal : nullptr;
+            if ((rc = gemm_ln(h, s, false, h->ffn, c.enc_ffn, L.fc2w, L.fc2b, Mp, Dv, c.enc_ffn, nullptr, h->x, h->ln_post_w, h->ln_post_b,
+                              c.enc_ln_eps, rows, h->hb, nullptr, addv, N, F, visual_out))) return rc;
         }
     }
-    // ln_post (+ per-frame temporal embedding, model.py:380); frames of a clip are already
-    // adjacent rows, so the concat along tokens (model.py:382) is the identity on this layout
-    const float* addv = c.num_frames > 0 ? h->temporal : nullptr;
-    // the fp32 visual features (58 MB at B=16, F=6) are written straight into the caller's buffer and only
-    // when asked for; the decoder consumes the bf16 copy
-    if ((rc = ln(h, s, h->x, Dv, h->ln_post_w, h->ln_post_b, c.enc_ln_eps, rows, Dv, visual_out, Dv, h->hb, Dv, addv, N, F))) return rc;
     return image_prefix(h, B, F * N, s);
 }
 
@@ -1073,7 +1087,7 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
         if (post) { if (hipMalloc(&tmp, (size_t)M * N * 4) != hipSuccess) return GITCAP_ERR_NOMEM; xo = tmp; a.out = tmp; }
         hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, resid ? EPI_BIAS_RESID_F32 : EPI_BIAS_F32, s);
         if (e == hipSuccess) {
-            LnArgs l{xo, N, gamma, beta, eps, M, N, post ? out_f32 : nullptr, N, (bf16_t*)out_bf16, N, nullptr, 1, 1};
+            LnArgs l{xo, N, gamma, beta, eps, M, N, post ? out_f32 : nullptr, N, (bf16_t*)out_bf16, N, nullptr, 1, 1, nullptr, nullptr, 0.f};
             e = launch_layernorm(l, s);
         }
         if (tmp) { (void)hipStreamSynchronize(s); (void)hipFree(tmp); }
@@ -1112,7 +1126,7 @@ int gitcap_dbg_attn_full(const void* qkv, void* ctx, int G, int S, int H, void* 
 
 int gitcap_dbg_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int D,
                          float* out_f32, void* out_bf16, void* stream) {
-    LnArgs a{x, D, gamma, beta, eps, rows, D, out_f32, D, (bf16_t*)out_bf16, D, nullptr, 1, 1};
+    LnArgs a{x, D, gamma, beta, eps, rows, D, out_f32, D, (bf16_t*)out_bf16, D, nullptr, 1, 1, nullptr, nullptr, 0.f};
     return launch_layernorm(a, (hipStream_t)stream) == hipSuccess ? 0 : GITCAP_ERR_HIP;
 }
 

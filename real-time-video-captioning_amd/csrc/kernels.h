@@ -12,7 +12,7 @@ enum GemmEpi {
     EPI_PATCH_F32 = 5,        // out f32 row (frame*N + 1 + patch) = acc + pos[1+patch]
     // 256x256 kernel only, N = 768 or 1024: the tiles of one row block exchange LayerNorm statistics (ln_canon.h)
     // and each normalises its own columns -> the LayerNorm launch behind the GEMM and its re-read disappear.
-    EPI_RESID_LN_PRE = 6,     // x = acc + bias + resid: out f32 = x, ln_out bf16 = LayerNorm(x)        (pre-LN ViT block)
+    EPI_RESID_LN_PRE = 6,     // x = acc + bias + resid: out f32 = x (nullable), ln_out bf16 = LayerNorm(x) [+ ln_add] (pre-LN ViT block; ln_post)
     EPI_RESID_LN_POST = 7     // x = acc + bias [+ resid]: out f32 = LayerNorm(x), ln_out bf16 = the same (post-LN decoder)
 };
 struct GemmArgs {
@@ -27,6 +27,9 @@ struct GemmArgs {
     // EPI_RESID_LN_*: LayerNorm of the output rows
     const float *ln_g, *ln_b; float ln_eps;
     bf16_t* ln_out; int ld_ln;    // bf16 LayerNorm output
+    const float* ln_add;          // nullable (PRE): LayerNorm output += ln_add[((row / ln_add_div) % ln_add_mod) * N + n]  (temporal embedding)
+    int ln_add_div, ln_add_mod;
+    float* ln_out_f32; int ld_ln_f32;   // nullable (PRE): fp32 copy of the LayerNorm output, rows < valid_rows only (caller's unpadded buffer)
     float2* ln_stats;             // [M][16] per-segment (mean, M2) exchanged between the tiles of a row block
     unsigned* ln_cnt;             // [M / 256][2] per row block {arrivals, generation}: zero before the first launch, self-resetting
 };
@@ -127,6 +130,9 @@ struct LnArgs {
     bf16_t* out_bf16; int ld_bf16;// nullable
     const float* add_vec;         // nullable: out += add_vec[((row / add_div) % add_mod) * D + c]
     int add_div, add_mod;
+    // optional SECOND LayerNorm of the first one's fp32 output (canonical widths only): out_f32 = LN(x), out_bf16 =
+    // LN2(LN(x)) -- ln_pre and the first block's LN1 of the ViT in one pass over the rows.  Same bits as two launches.
+    const float* gamma2; const float* beta2; float eps2;
 };
 hipError_t launch_layernorm(const LnArgs& a, hipStream_t s);
 

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
         rstd = rsqrtf(wave_sum(q) / (float)a.D + a.eps);
     }
     const float* addv = a.add_vec ? a.add_vec + (size_t)((row / a.add_div) % a.add_mod) * a.D : nullptr;
+    const bool two = CANON && a.gamma2 != nullptr;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
@@ -71,11 +72,41 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
             }
             if (addv) y += *(const f32x4*)(addv + c);
             if (a.out_f32) *(f32x4*)(a.out_f32 + (size_t)row * a.ld_f32 + c) = y;
-            if (a.out_bf16) {
+            if (a.out_bf16 && !two) {
                 uint2 o;
                 o.x = pack_bf2(y[0], y[1]);
                 o.y = pack_bf2(y[2], y[3]);
                 *(uint2*)(a.out_bf16 + (size_t)row * a.ld_bf16 + c) = o;
+            }
+            v[i] = y;
+        }
+    }
+    if (CANON) {
+        if (two) {       // second LayerNorm over the values just produced (what a second launch would read back)
+            float2 st[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) st[i] = ln_seg_stats(v[i]);
+            auto seg = [&](int sidx) {
+                const int src = (sidx & 3) * 16;
+                return float2{__shfl(st[sidx >> 2].x, src), __shfl(st[sidx >> 2].y, src)};
+            };
+            float mean2, rstd2;
+            if (a.D == 768) ln_merge<12>(seg, a.eps2, mean2, rstd2);
+            else if (a.D == 1024) ln_merge<16>(seg, a.eps2, mean2, rstd2);
+            else if (a.D == 128) ln_merge<2>(seg, a.eps2, mean2, rstd2);
+            else if (a.D == 64) ln_merge<1>(seg, a.eps2, mean2, rstd2);
+            else if (a.D == 256) ln_merge<4>(seg, a.eps2, mean2, rstd2);
+            else ln_merge<8>(seg, a.eps2, mean2, rstd2);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = i * 256 + lane * 4;
+                if (c < a.D && a.out_bf16) {
+                    const f32x4 y = ln_apply(v[i], mean2, rstd2, *(const f32x4*)(a.gamma2 + c), *(const f32x4*)(a.beta2 + c));
+                    uint2 o;
+                    o.x = pack_bf2(y[0], y[1]);
+                    o.y = pack_bf2(y[2], y[3]);
+                    *(uint2*)(a.out_bf16 + (size_t)row * a.ld_bf16 + c) = o;
+                }
             }
         }
     }
@@ -500,6 +531,7 @@ hipError_t launch_layernorm(const LnArgs& a, hipStream_t s) {
     const int grid = (a.rows + 3) / 4;
     const int nv = (a.D + 255) / 256;
     const bool canon = a.D == 64 || a.D == 128 || a.D == 256 || a.D == 512 || a.D == 768 || a.D == 1024;
+    if (a.gamma2 && (!canon || !a.beta2 || !a.out_bf16)) return hipErrorInvalidValue;
     switch (nv * 2 + (canon ? 1 : 0)) {
         case 2: hipLaunchKernelGGL((layernorm_kernel<1, false>), dim3(grid), dim3(256), 0, s, a); break;
         case 3: hipLaunchKernelGGL((layernorm_kernel<1, true>), dim3(grid), dim3(256), 0, s, a); break;
