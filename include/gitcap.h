@@ -208,7 +208,7 @@ int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launche
 /* Kernel-level test hooks (tests/test_kernels_gpu.py, tools/gemm_bench.py): run ONE kernel on
  * caller-owned device buffers.  gemm: out[m][n] = sum_k A[m][k]*W[n][k] (+epilogue `epi` of
  * csrc/kernels.h: 0 bias->bf16, 1 bias+QuickGELU->bf16, 2 bias+GELU->bf16, 3 bias+resid->f32,
- * 4 bias->f32); A [M][K] bf16, W [N][K] bf16, M % 128 == 0; tile = 128 or 256 (the two product kernels). */
+ * 4 bias->f32); A [M][K] bf16, W [N][K] bf16; tile = 64, 128 or 256 (the three product tile kernels: M, N multiples of the tile). */
 int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float* resid, void* out,
                     int M, int N, int K, int epi, int tile, void* stream);
 /* GEMM + bias [+ resid] followed by LayerNorm of the output rows (N = 768 or 1024).  post = 0: out_f32 = x = A W^T + bias +
@@ -220,7 +220,8 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
                        int fused, int tile, void* stream);
 /* Speed-only switches at run time (what the GITCAP_* environment variables set once per process; INTEGRATION.md par. 9), so that
  * one process can check that results do not depend on them.  key 0: GEMM + LayerNorm epilogue on/off; 1: one/two-row prologue
- * on/off; 2: 256x256-tile threshold; 3: 128x128-tile threshold.  Returns the previous value (< 0: bad key).  Not thread safe. */
+ * on/off; 2: 256x256-tile threshold; 3: 128x128-tile threshold.  Returns the previous value (< 0: bad key).  The switches are process-wide atomics: a call on another thread sees either value,
+ * and either value gives the same bits. */
 int gitcap_dbg_config(int key, int value);
 /* attn_full: qkv [G*S][3*H*64] bf16 -> ctx [G*S][H*64] bf16 */
 int gitcap_dbg_attn_full(const void* qkv, void* ctx, int G, int S, int H, void* stream);

@@ -172,3 +172,22 @@ def beam_search(input_ids: torch.Tensor, step: Callable[[torch.Tensor], torch.Te
     if num_keep_best == 1:
         decoded = decoded.squeeze(1)
     return decoded, logprobs, saved_logits
+
+
+def teacher_output(predictions: torch.Tensor, logits_dict, cap: str, num_beams: int = 4) -> torch.Tensor:
+    """Oracle of the winning-beam logit gather of ``GenerativeImageTextTeacher.forward``
+    (/root/reference/src/models/model.py:771-788), for ONE clip:
+
+    * ``predictions`` [1, max_steps] -- the clip's best hypothesis (``result['predictions']``, :771/:780),
+    * ``logits_dict`` -- per search step the [num_beams, V] logits of that clip's beams (``result['logits_dict']``, :772/:776),
+    * ``cap`` -- the decoded caption (:771); n = min(words in cap, saved steps) (:772).
+
+    For each of the first n predicted words: the beam whose logit AT THAT WORD is highest (:784-785), then that beam's whole
+    logit row (:787-788) -> [1, n, V].  The reference hard-codes 4 beams (:782); ``num_beams`` keeps that as the default."""
+    import numpy as np
+    n = min(len(cap.split(' ')), len(logits_dict))
+    dist = torch.from_numpy(np.array([np.asarray(l) for l in logits_dict[:n]]))               # [n, beams, V]   (:776)
+    word_tokens = predictions[0, 1:n + 1].cpu()[:, None, None].expand(-1, num_beams, -1)       # [n, beams, 1]   (:780-781)
+    idx = torch.gather(dist, dim=2, index=word_tokens).squeeze(-1).argmax(dim=1)              # [n]             (:784-785)
+    idx = idx[:, None, None].expand(-1, -1, dist.shape[-1])                                  # (:787)
+    return torch.gather(dist, dim=1, index=idx).squeeze(1)[None, ...]                        # [1, n, V]       (:788)

@@ -35,6 +35,7 @@
 // XOR-swizzled by (row>>1)&7 on the DMA SOURCE address and again on the read (conflict-free
 // ds_read_b128 for the 16x16x32 operand map, see common.h).
 #include "gemm_epilogue.h"
+#include "host_logic.h"
 
 namespace {
 
@@ -55,8 +56,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     const int grp = wid >> 2;                      // ping-pong group
     const int wn = wid >> 2, wm = wid & 3;
     const int ntn = a.N >> 8;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = lid / ntn, tn = lid - tm * ntn;
+    int tm, tn;
+    if (EPI == EPI_RESID_LN_PRE || EPI == EPI_RESID_LN_POST) {
+        // The tiles of a row block wait for each other (statistics exchange): they must never straddle two XCDs' dispatch
+        // sequences.  Workgroup b runs on XCD b % 8 as that XCD's (b / 8)-th workgroup, so XCD x is handed WHOLE row blocks
+        // (a balanced contiguous range) whose ntn tiles are consecutive in its sequence: a waiting tile only ever waits
+        // for a sibling that is resident on the same XCD or next in line for it.  The grid is padded to
+        // 8 * ntn * ceil(row blocks / 8); the surplus workgroups (last in every sequence) leave at once.
+        if (!ln_tile_of_block(blockIdx.x, a.M >> 8, ntn, &tm, &tn)) return;     // host_logic.h (tested on the CPU)
+    } else {
+        const int lid = xcd_remap(blockIdx.x, gridDim.x);
+        tm = lid / ntn; tn = lid - tm * ntn;
+    }
     const int m0 = tm << 8, n0 = tn << 8;
 
     // ---- LDS-DMA source addresses: wave w moves pieces 2w, 2w+1 (8 rows each) of every half-tile
@@ -275,7 +286,8 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int grid = (a.M >> 8) * (a.N >> 8);
+    constexpr bool LN = (EPI == EPI_RESID_LN_PRE || EPI == EPI_RESID_LN_POST);
+    const int grid = LN ? ln_grid_size(a.M >> 8, a.N >> 8) : (a.M >> 8) * (a.N >> 8);   // LN: whole row blocks per XCD
     hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS, s, a);
     return hipGetLastError();
 }

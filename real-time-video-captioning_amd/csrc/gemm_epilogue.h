@@ -1,5 +1,5 @@
-// LDS-staged epilogue shared by the 256x256 (gemm256.hip, gemm256p.hip uses its own) and 256x128 (gemm2b.hip)
-// kernels: both give a wave the same 128(n) x 64(m) accumulator block acc[x][i][y][j]
+// LDS-staged epilogue of the 256x256 kernel (gemm256.hip; the experimental tile kernels under tools/experiments/ reuse it):
+// a wave holds a 128(n) x 64(m) accumulator block acc[x][i][y][j]
 // (n = x*64 + i*16 + 4*(lane>>4) + r, m = y*32 + j*16 + (lane&15)).
 //
 // The accumulator layout (lane = one m, 4 consecutive n) would scatter 32-byte pieces over 16 rows
@@ -108,10 +108,15 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // (PRE) and stays in registers (they replace the accumulators), the segment statistics go to LDS, then -- the tile's 4
 // segments per row together -- to global memory with 16-byte agent-scope stores; one arrival per tile on the row block's
 // barrier; then every wave fetches the 128 B of statistics of each of its 64 rows (coalesced), merges the NSEG segments
-// in the canonical order and normalises its registers.  Tiles of a row block have consecutive logical ids (same or adjacent
-// dispatch), and a tile never waits for anything before it publishes, so the wait is bounded by the slowest sibling;
-// workgroups are dispatched in index order, so a waiting tile can only wait for a tile that is resident or that will
-// be dispatched as soon as any tile with all siblings resident retires: no deadlock; the spin is bounded + trap.
+// in the canonical order and normalises its registers.  The tiles of a row block are consecutive workgroups of ONE XCD's
+// dispatch sequence (gemm256.hip hands every XCD whole row blocks), and a tile never waits for anything before it
+// publishes, so the wait is bounded by the slowest sibling; an XCD dispatches its workgroups in index order, so a
+// waiting tile can only wait for a tile that is resident on the same XCD or that is dispatched as soon as any tile of
+// that XCD with all siblings resident retires: no deadlock as long as an XCD can hold N/256 workgroups of this kernel
+// at once ("co-residency"); the spin is bounded + trap.  Ordering: every wave drains its write-through
+// (sc1) statistics stores with s_waitcnt vmcnt(0) before the workgroup barrier that precedes the arrival, the arrival and
+// the poll are agent-scope atomics, and the statistics are fetched with sc1 loads issued after the poll succeeded (the
+// "write-through store; drain; flag" form of MI355X_MICROARCH.md; agent-scope fences measured 5.4 vs 1.9 us per exchange).
 template <bool POST>
 __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f32x4 (&acc)[2][4][2][2], char* smem,
                                                       const int m0, const int n0, const int tm, const int tn,

@@ -5,6 +5,7 @@
 #include "host_util.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -19,8 +20,11 @@
 #define GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, s) ((tile) == 256 ? launch_gemm256(a, epi, s) : (tile) == 64 ? launch_gemm64(a, epi, s) : launch_gemm(a, epi, s))
 #endif
 
-// shared with student.hip; gitcap_dbg_config can flip it
-bool g_row_prologue = getenv("GITCAP_NO_ROW_PROLOGUE") == nullptr;
+// Speed-only switches (results do not depend on them: tests/test_parity_gpu.py).  Process-wide, set once from the
+// environment; gitcap_dbg_config (a test hook) may flip them at run time, so they are atomics: an entry point running on
+// another thread reads a consistent value at each use and either value gives the same bits.
+// g_row_prologue is shared with student.hip.
+std::atomic<bool> g_row_prologue{getenv("GITCAP_NO_ROW_PROLOGUE") == nullptr};
 
 namespace {
 
@@ -134,9 +138,9 @@ std::string g_create_err;
 // another one to keep up with the image pass.
 const int g_txt_streams = getenv("GITCAP_TXT_STREAMS") ? std::max(1, std::min(4, atoi(getenv("GITCAP_TXT_STREAMS")))) : 2;
 // 256x256-tile count below which the 128x128 kernel is used (GITCAP_GEMM_SMALL_TILES=0 disables the switch)
-int g_small_tiles = getenv("GITCAP_GEMM_SMALL_TILES") ? atoi(getenv("GITCAP_GEMM_SMALL_TILES")) : 128;
+std::atomic<int> g_small_tiles{getenv("GITCAP_GEMM_SMALL_TILES") ? atoi(getenv("GITCAP_GEMM_SMALL_TILES")) : 128};
 // 128x128-tile count below which the 64x64 kernel is used (GITCAP_GEMM_TINY_TILES=0 disables the switch)
-int g_tiny_tiles = getenv("GITCAP_GEMM_TINY_TILES") ? atoi(getenv("GITCAP_GEMM_TINY_TILES")) : 200;     // measured crossover (tools/gemm_tiles_small.py): 180 -> 64x64, 228 -> 128x128
+std::atomic<int> g_tiny_tiles{getenv("GITCAP_GEMM_TINY_TILES") ? atoi(getenv("GITCAP_GEMM_TINY_TILES")) : 200};     // measured crossover (tools/gemm_tiles_small.py): 180 -> 64x64, 228 -> 128x128
 
 // Tile kernel selection.  Few 256x256 tiles (small batches: one 6-frame clip is 5 x 3..12 tiles for 256 CUs) leave
 // most of the chip idle: below g_small_tiles tiles the 128x128 kernel (4x the workgroups, two per CU) is used
@@ -148,27 +152,6 @@ hipError_t launch_gemm_auto(const GemmArgs& a, int epi, hipStream_t s) {
     if ((a.M & 63) == 0 && (a.N & 63) == 0 && ((a.M & 127) || (a.N & 127) || (a.M >> 7) * (a.N >> 7) < g_tiny_tiles))
         return launch_gemm64(a, epi, s);
     return launch_gemm(a, epi, s);
-}
-
-// OCP e4m3fn code of x, or -1 when x is not exactly representable (bias 7, 3 mantissa bits, max 448, no infinities)
-int host_e4m3_exact(float x) {
-    const int sign = std::signbit(x) ? 0x80 : 0;
-    const float a = std::fabs(x);
-    if (a == 0.f) return sign;
-    if (!(a <= 448.f)) return -1;
-    int e;
-    const float m = std::frexp(a, &e);          // a = m * 2^e, m in [0.5, 1)
-    const int E = e - 1 + 7;                    // a = (2m) * 2^(e-1)
-    if (E >= 1) {
-        const float f = (2.f * m - 1.f) * 8.f;  // mantissa field
-        const int M = (int)f;
-        if ((float)M != f) return -1;
-        return sign | (E << 3) | M;
-    }
-    const float f = std::ldexp(a, 9);           // subnormal: a = M * 2^-9
-    const int M = (int)f;
-    if ((float)M != f || M < 1 || M > 7) return -1;
-    return sign | M;
 }
 
 int fail(const gitcap* h, int code, const std::string& msg) {
@@ -227,43 +210,6 @@ struct ProfScope {
     ~ProfScope() { if (r) (void)hipEventRecord(r->b, s); }
 };
 
-// canonical names -> (shape, is_gemm_weight); mirrors gitcap/weights.py:canonical_shapes
-void expected_shapes(const gitcap_config& c, std::vector<std::pair<std::string, std::vector<int64_t>>>& out) {
-    const int64_t Dv = c.enc_width, D = c.dec_width, V = c.vocab_size;
-    const int64_t G = c.image_size / c.patch_size, N = G * G + 1, pd = 3LL * c.patch_size * c.patch_size;
-    auto add = [&](const std::string& n, std::vector<int64_t> s) { out.emplace_back(n, std::move(s)); };
-    add("enc.patch_w", {Dv, pd}); add("enc.cls", {Dv}); add("enc.pos", {N, Dv});
-    add("enc.ln_pre.w", {Dv}); add("enc.ln_pre.b", {Dv}); add("enc.ln_post.w", {Dv}); add("enc.ln_post.b", {Dv});
-    for (int i = 0; i < c.enc_layers; ++i) {
-        const std::string p = "enc.L" + std::to_string(i) + ".";
-        add(p + "ln1.w", {Dv}); add(p + "ln1.b", {Dv});
-        add(p + "qkv.w", {3 * Dv, Dv}); add(p + "qkv.b", {3 * Dv});
-        add(p + "proj.w", {Dv, Dv}); add(p + "proj.b", {Dv});
-        add(p + "ln2.w", {Dv}); add(p + "ln2.b", {Dv});
-        add(p + "fc1.w", {c.enc_ffn, Dv}); add(p + "fc1.b", {c.enc_ffn});
-        add(p + "fc2.w", {Dv, c.enc_ffn}); add(p + "fc2.b", {Dv});
-    }
-    add("temporal", {std::max(1, c.num_frames), Dv});
-    add("vproj.w", {D, Dv}); add("vproj.b", {D}); add("vproj.ln.w", {D}); add("vproj.ln.b", {D});
-    add("txt.word", {V, D}); add("txt.pos", {c.max_text_pos, D}); add("txt.ln.w", {D}); add("txt.ln.b", {D});
-    for (int i = 0; i < c.dec_layers; ++i) {
-        const std::string p = "dec.L" + std::to_string(i) + ".";
-        add(p + "qkv.w", {3 * D, D}); add(p + "qkv.b", {3 * D});
-        add(p + "ao.w", {D, D}); add(p + "ao.b", {D});
-        add(p + "ln1.w", {D}); add(p + "ln1.b", {D});
-        add(p + "fc1.w", {c.dec_ffn, D}); add(p + "fc1.b", {c.dec_ffn});
-        add(p + "fc2.w", {D, c.dec_ffn}); add(p + "fc2.b", {D});
-        add(p + "ln2.w", {D}); add(p + "ln2.b", {D});
-    }
-    add("head.w", {V, D}); add("head.b", {V});
-}
-
-bool is_gemm_weight(const std::string& n) {
-    if (n == "enc.patch_w" || n == "vproj.w" || n == "head.w") return true;
-    auto ends = [&](const char* s) { size_t l = strlen(s); return n.size() >= l && n.compare(n.size() - l, l, s) == 0; };
-    return ends("qkv.w") || ends("proj.w") || ends("fc1.w") || ends("fc2.w") || ends("ao.w");
-}
-
 template <typename T>
 int ws_alloc(gitcap* h, T** p, size_t count) {
     void* q = nullptr;
@@ -317,7 +263,7 @@ int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef
 // Large launches run both inside the 256x256 kernel (EPI_RESID_LN_*: the tiles of a row block exchange segment
 // statistics); small ones the 128x128 kernel + the row kernel.  Both give the same bits (ln_canon.h).
 // GITCAP_NO_GEMM_LN=1 (diagnosis / A-B only) keeps every LayerNorm a launch of its own.
-bool g_fuse_ln = getenv("GITCAP_NO_GEMM_LN") == nullptr;
+std::atomic<bool> g_fuse_ln{getenv("GITCAP_NO_GEMM_LN") == nullptr};
 
 int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const WRef& W, const float* bias, int M, int N,
             int K, float* xout, const float* resid, const float* ln_g, const float* ln_b, float eps, int rows,
@@ -673,29 +619,20 @@ int gitcap_load_tensor(gitcap_t* h, const char* name, const float* data, const i
         std::vector<uint8_t> q((size_t)prow * pcol, 0);
         std::vector<float> sc((size_t)prow, 1.0f);
         for (int64_t r = 0; r < rows; ++r) {
-            float amax = 0.f;
-            for (int64_t k = 0; k < cols; ++k) amax = std::max(amax, std::fabs(data[(size_t)r * cols + k]));
-            int e = 0;
-            if (amax > 0.f) { (void)std::frexp(amax / 448.0f, &e); if (std::ldexp(1.0f, e - 1) * 448.0f >= amax) --e; }
-            const float scale = std::ldexp(1.0f, e);
-            sc[r] = scale;
-            for (int64_t k = 0; k < cols; ++k) {
-                int code = host_e4m3_exact(data[(size_t)r * cols + k] / scale);
-                if (code < 0)
-                    return fail(h, GITCAP_ERR_ARG, std::string("load_tensor: ") + name + " holds a value that is not e4m3 x 2^k "
-                                "(quantise first: gitcap.weights.quantize_weights_fp8)");
-                q[(size_t)r * pcol + k] = (uint8_t)code;
-            }
+            sc[r] = host_e4m3_row_scale(data + (size_t)r * cols, cols);
+            if (!host_e4m3_encode_row(data + (size_t)r * cols, cols, sc[r], q.data() + (size_t)r * pcol))
+                return fail(h, GITCAP_ERR_ARG, std::string("load_tensor: ") + name + " holds a value that is not e4m3 x 2^k "
+                            "(quantise first: gitcap.weights.quantize_weights_fp8)");
         }
-        float* dsc = nullptr;
-        HIP_OK(h, hipMalloc(&t.p, q.size()));
-        HIP_OK(h, hipMemcpy(t.p, q.data(), q.size(), hipMemcpyHostToDevice));
+        // the scale buffer is owned by h->wscale from the moment it exists, the codes by t.p: an error below leaks nothing
+        float*& dsc = h->wscale[name];
+        if (dsc) { (void)hipFree(dsc); dsc = nullptr; }
         HIP_OK(h, hipMalloc((void**)&dsc, sc.size() * 4));
         HIP_OK(h, hipMemcpy(dsc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
-        auto it2 = h->wscale.find(name);
-        if (it2 != h->wscale.end() && it2->second) (void)hipFree(it2->second);
-        h->wscale[name] = dsc;
+        HIP_OK(h, hipMalloc(&t.p, q.size()));
         t.bytes = (int64_t)(q.size() + sc.size() * 4);
+        h->weight_bytes += t.bytes;
+        HIP_OK(h, hipMemcpy(t.p, q.data(), q.size(), hipMemcpyHostToDevice));
     } else if (t.bf16) {
         // GEMM weights: bf16, rows padded to 16 (zero rows), patch-embed K padded to a multiple of 64
         const int64_t prow = pad_to((int)rows, 16), pcol = (strcmp(name, "enc.patch_w") == 0) ? h->Kp : cols;
@@ -703,15 +640,16 @@ int gitcap_load_tensor(gitcap_t* h, const char* name, const float* data, const i
         for (int64_t r = 0; r < rows; ++r)
             for (int64_t k = 0; k < cols; ++k) hb[(size_t)r * pcol + k] = host_f2bf(data[(size_t)r * cols + k]);
         HIP_OK(h, hipMalloc(&t.p, hb.size() * 2));
-        HIP_OK(h, hipMemcpy(t.p, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
         t.bytes = (int64_t)hb.size() * 2;
+        h->weight_bytes += t.bytes;
+        HIP_OK(h, hipMemcpy(t.p, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
     } else {
         const size_t bytes = (size_t)rows * cols * 4;
         HIP_OK(h, hipMalloc(&t.p, bytes));
-        HIP_OK(h, hipMemcpy(t.p, data, bytes, hipMemcpyHostToDevice));
         t.bytes = (int64_t)bytes;
+        h->weight_bytes += t.bytes;
+        HIP_OK(h, hipMemcpy(t.p, data, bytes, hipMemcpyHostToDevice));
     }
-    h->weight_bytes += t.bytes;
     t.loaded = true;
     h->finalized = false;
     return 0;
@@ -938,7 +876,7 @@ int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max
     GUARD(h);
     int rc = greedy_check(h, max_len, stop, ids_out);
     if (rc) return rc;
-    const int slot = h->next_ticket % gitcap::NSLOT;
+    const int slot = ticket_slot(h->next_ticket, gitcap::NSLOT);
     gitcap::Slot& sl = h->slots[slot];
     select_slot(h, slot);
     // the image pass may start once the caller's stream has produced `frames` ...
@@ -960,9 +898,9 @@ int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max
 int gitcap_greedy_wait(gitcap_t* h, int ticket, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "greedy_wait: null handle");
     GUARD(h);
-    if (ticket < 0 || ticket >= h->next_ticket || ticket < h->next_ticket - gitcap::NSLOT)
+    if (!ticket_waitable(ticket, h->next_ticket, gitcap::NSLOT))
         return fail(h, GITCAP_ERR_ARG, "greedy_wait: ticket is not one of the submissions in flight");
-    HIP_OK(h, hipStreamWaitEvent((hipStream_t)stream, h->slots[ticket % gitcap::NSLOT].ev_dec, 0));
+    HIP_OK(h, hipStreamWaitEvent((hipStream_t)stream, h->slots[ticket_slot(ticket, gitcap::NSLOT)].ev_dec, 0));
     return 0;
 }
 
@@ -1111,10 +1049,10 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
 int gitcap_dbg_config(int key, int value) {
     int old = -1;
     switch (key) {
-        case 0: old = g_fuse_ln; g_fuse_ln = value != 0; break;
-        case 1: old = g_row_prologue; g_row_prologue = value != 0; break;
-        case 2: old = g_small_tiles; g_small_tiles = value; break;
-        case 3: old = g_tiny_tiles; g_tiny_tiles = value; break;
+        case 0: old = g_fuse_ln.exchange(value != 0); break;
+        case 1: old = g_row_prologue.exchange(value != 0); break;
+        case 2: old = g_small_tiles.exchange(value); break;
+        case 3: old = g_tiny_tiles.exchange(value); break;
         default: return GITCAP_ERR_ARG;
     }
     return old;

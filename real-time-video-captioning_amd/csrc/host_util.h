@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "host_logic.h"      // pad_to, host_f2bf, e4m3 encodings, tensor table (HIP-free: also built under ASan for the CPU)
+
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -13,16 +15,6 @@ struct DevTensor {
     bool loaded = false;
     int64_t bytes = 0;            // device bytes held (incl. row scales)
 };
-
-inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
-
-inline uint16_t host_f2bf(float f) {    // round-to-nearest-even, NaN stays NaN
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
 
 // Makes a handle's device current for the duration of an entry point and restores the caller's.
 struct DeviceGuard {

@@ -1,6 +1,7 @@
 // Launcher declarations for the gfx950 kernels behind libgitcap's C ABI.
 #pragma once
 #include "common.h"
+#include <atomic>
 
 // ---- big-tile bf16 MFMA GEMM:  C[m][n] = sum_k A[m][k] * W[n][k]  (+ epilogue) -------------
 enum GemmEpi {
@@ -64,7 +65,7 @@ struct SkinnyArgs {
         float* xf;                         // [M][K]
     } ln;
 };
-extern bool g_row_prologue;                                 // gitcap.hip: GITCAP_NO_ROW_PROLOGUE / gitcap_dbg_config(1, .)
+extern std::atomic<bool> g_row_prologue;                                 // gitcap.hip: GITCAP_NO_ROW_PROLOGUE / gitcap_dbg_config(1, .)
 bool skinny_row_prologue_ok(int M, int K, bool fp8);         // shapes the row-prologue form is instantiated for
 hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s);
 bool skinny_full_ok(int K);                                  // K depths launch_skinny is instantiated for

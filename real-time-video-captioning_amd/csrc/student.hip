@@ -145,7 +145,7 @@ int sfail(const gitcap_student* h, int code, const std::string& msg) {
     } while (0)
 #define S_GUARD(h) DeviceGuard guard_((h)->device); if (!guard_.ok) return sfail(h, GITCAP_ERR_HIP, "cannot select the handle's device")
 
-bool is_gemm_weight(const std::string& n) {
+bool student_is_gemm_weight(const std::string& n) {
     auto ends = [&](const char* s) { size_t l = strlen(s); return n.size() >= l && n.compare(n.size() - l, l, s) == 0; };
     return n == "linear.weight" || ends("in_proj_weight") || ends("out_proj.weight") || ends("linear1.weight") || ends("linear2.weight");
 }
@@ -323,7 +323,7 @@ int gitcap_student_create(const gitcap_student_config* cfg, int device, gitcap_s
     for (auto& kv : shapes) {
         DevTensor t;
         t.shape = kv.second;
-        t.bf16 = is_gemm_weight(kv.first);
+        t.bf16 = student_is_gemm_weight(kv.first);
         h->w[kv.first] = t;
     }
     *out = h;

@@ -75,15 +75,19 @@ class CaptionGatherRing:
         self.n_clips, self.L, self.nbuf = n_clips, L, nbuf
         self.gloo = dist.get_backend(group) == "gloo"
         self.bufs = [torch.empty((self.world * self.bmax, L), dtype=dtype, device=device) for _ in range(nbuf)]
-        self.works = []                                   # (work, buffer index, local ids kept alive)
+        # one entry per buffer: (work, local ids kept alive) of the gather that last wrote it, or None.  Bounded: a
+        # long-running captioner pushes for ever and only the last nbuf gathers can still be in flight.
+        self.works = [None] * nbuf
+        self.pushed = 0
 
     def push(self, ids: torch.Tensor, join: bool = False):
         lo, hi = self.sizes[self.rank]
         if tuple(ids.shape) != (hi - lo, self.L):
             raise ValueError(f"local block {tuple(ids.shape)} does not match shard_range {(hi - lo, self.L)}")
-        i = len(self.works) % self.nbuf
-        if len(self.works) >= self.nbuf:                  # the buffer's previous gather (nbuf batches ago)
-            self.works[len(self.works) - self.nbuf][0].wait()
+        i = self.pushed % self.nbuf
+        if self.works[i] is not None:                     # the buffer's previous gather (nbuf batches ago): wait, then drop it
+            self.works[i][0].wait()
+            self.works[i] = None
         pad = ids
         if ids.shape[0] < self.bmax:
             pad = torch.cat([ids, ids.new_zeros((self.bmax - ids.shape[0], self.L))], 0)
@@ -93,7 +97,8 @@ class CaptionGatherRing:
             w = dist.all_gather(list(buf.view(self.world, self.bmax, self.L).unbind(0)), pad, group=self.group, async_op=True)
         else:
             w = dist.all_gather_into_tensor(buf, pad, group=self.group, async_op=True)   # rank-major: row i = global clip i
-        self.works.append((w, i, pad))
+        self.works[i] = (w, pad)
+        self.pushed += 1
         if join:
             w.wait()
         return w, buf
@@ -105,6 +110,13 @@ class CaptionGatherRing:
         return torch.cat([buf[r * self.bmax: r * self.bmax + (hi - lo)] for r, (lo, hi) in enumerate(self.sizes)], 0)
 
     def fence(self):
-        for w, _, _ in self.works[-self.nbuf:]:
-            w.wait()
+        for k in range(self.nbuf):                        # oldest first
+            i = (self.pushed + k) % self.nbuf
+            if self.works[i] is not None:
+                self.works[i][0].wait()
+                self.works[i] = None                      # completed: release the work handle and the padded ids
         dist.barrier(group=self.group)
+
+    def in_flight(self) -> int:
+        """Entries the ring still holds (work handle + padded ids): at most nbuf, however many batches were pushed."""
+        return sum(e is not None for e in self.works)

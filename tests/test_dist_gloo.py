@@ -60,11 +60,15 @@ def _ring_worker(rank, world, port, n_clips, L, nbatch, nbuf, q):
                 ids[i, 0] = 101
             w, buf = ring.push(ids, join=(b % 3 == 0))    # some joined at once, most a few batches later
             outs.append((w, buf))
+            # the ring is bounded: a long-running captioner must not accumulate work handles / padded ids
+            assert ring.in_flight() <= nbuf and len(ring.works) == nbuf, (ring.in_flight(), nbuf)
             if len(outs) > 2:                             # consume two batches behind, like bench.py's pipeline
                 w0, buf0 = outs[-3]
                 w0.wait()
                 q.put((rank, b - 2, ring.rows(buf0).tolist()))
+                outs[-3] = None                           # (the test itself keeps nothing alive either)
         ring.fence()
+        assert ring.in_flight() == 0
         for b in (nbatch - 2, nbatch - 1):
             q.put((rank, b, ring.rows(outs[b][1]).tolist()))
     finally:
@@ -76,7 +80,7 @@ def test_two_rank_gather_ring(n_clips):
     """The asynchronous gather ring bench.py uses for N > 1 (>= 2 x nbuf batches, ragged last shard when
     n_clips = 5): every batch arrives complete and in global clip order on every rank."""
     world, L, nbuf = 2, 6, 3
-    nbatch = 2 * nbuf + 2
+    nbatch = 12 * nbuf + 2                                # many times the ring size: the ring must stay at nbuf entries
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 30100 + (os.getpid() % 500) + n_clips

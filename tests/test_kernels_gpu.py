@@ -64,9 +64,9 @@ def test_gemm_identity_weight_asymmetric_input(lib):
 
 
 def test_gemm_tile_variants_are_bitwise_equal(lib):
-    """Every tile kernel accumulates each output over ascending k with the same MFMA, so the 128x128
-    fallback, the persistent and the two-workgroup variants must reproduce the product kernel bit for bit
-    (this is what makes results independent of which kernel a shape is routed to)."""
+    """Every tile kernel accumulates each output over ascending k with the same MFMA, so the 128x128 and 64x64
+    kernels must reproduce the 256x256 product kernel bit for bit (this is what makes results independent of which
+    kernel a shape is routed to)."""
     M, N, K = 1024, 768, 768
     g = torch.Generator(device="cuda").manual_seed(7)
     A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
@@ -84,11 +84,15 @@ def test_gemm_tile_variants_are_bitwise_equal(lib):
 
 
 @pytest.mark.parametrize("M,N,K,post,with_resid", [(1024, 768, 768, 0, True), (1024, 768, 768, 1, True), (768, 768, 3072, 1, False),
-                                                   (512, 1024, 256, 0, True), (19200, 768, 768, 0, True), (19200, 768, 3072, 1, True)])
+                                                   (512, 1024, 256, 0, True), (19200, 768, 768, 0, True), (19200, 768, 3072, 1, True),
+                                                   (75776, 768, 768, 0, True), (2304, 1024, 1024, 1, True)])
 def test_gemm_layernorm_epilogue_equals_gemm_then_layernorm(lib, M, N, K, post, with_resid):
     """The residual GEMM that normalises its own rows (tiles of a 256-row block exchange segment statistics) must give the
     bits of the GEMM (either tile kernel) followed by the row kernel -- which of them runs depends on the batch size --
-    and both must be LayerNorm(A W^T + bias + resid) to fp32 accuracy.  19200 rows = the bench shape (225 tiles, one round)."""
+    and both must be LayerNorm(A W^T + bias + resid) to fp32 accuracy.  19200 rows = the bench shape (225 tiles, one round);
+    75776 rows = 888 tiles, several rounds on 256 CUs: the tiles of a row block must stay consecutive workgroups of one XCD
+    (a tile that waits for a sibling which is queued behind it would spin until the trap); 2304 x 1024 = 9 row blocks of 4
+    tiles, not a multiple of the 8 XCDs (padded grid, surplus workgroups leave at once)."""
     g = torch.Generator(device="cuda").manual_seed(11)
     A = torch.randn(M, K, device="cuda", generator=g).bfloat16()
     W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()

@@ -254,3 +254,19 @@ def test_device_beam_search_vs_committed_golden():
                 else:
                     assert abs(glp[b] - wlp[b]) < 0.02, (name, b, got[b], want[b])
     assert exact >= 8, exact        # of 12 (3 cases x 2 clips x 2 drivers)
+
+
+def test_oracle_teacher_output_known_answer():
+    """oracle/search_oracle.py: teacher_output (model.py:771-788) on a hand-made case: per predicted word the logits of
+    the beam that scores THAT word highest."""
+    from oracle.search_oracle import teacher_output
+    V, beams = 5, 4
+    step0 = np.zeros((beams, V), np.float32); step0[2, 3] = 7.0; step0[2, 0] = -1.0      # word 3: beam 2 wins
+    step1 = np.zeros((beams, V), np.float32); step1[0, 1] = 2.0; step1[3, 1] = 2.5      # word 1: beam 3 wins
+    step2 = np.ones((beams, V), np.float32)                                             # never reached: cap has 2 words
+    pred = torch.tensor([[101, 3, 1, 4, 102]])
+    out = teacher_output(pred, [step0, step1, step2], "w3 w1")
+    assert out.shape == (1, 2, V)
+    assert np.array_equal(out[0, 0].numpy(), step0[2]) and np.array_equal(out[0, 1].numpy(), step1[3])
+    # n is capped by the number of saved steps (model.py:772)
+    assert teacher_output(pred, [step0], "w3 w1 w4").shape == (1, 1, V)
