@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     const int wn = wid >> 2, wm = wid & 3;
     const int ntn = a.N >> 8;
     int tm, tn;
-    if (EPI == EPI_RESID_LN_PRE || EPI == EPI_RESID_LN_POST) {
+    if ((EPI == EPI_RESID_LN_PRE || EPI == EPI_RESID_LN_POST) && a.ln_rowblock_map) {
         // The tiles of a row block wait for each other (statistics exchange): they must never straddle two XCDs' dispatch
         // sequences.  Workgroup b runs on XCD b % 8 as that XCD's (b / 8)-th workgroup, so XCD x is handed WHOLE row blocks
         // (a balanced contiguous range) whose ntn tiles are consecutive in its sequence: a waiting tile only ever waits
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
 }
 
 template <int EPI>
-hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
+hipError_t launch_t(const GemmArgs& a0, hipStream_t s) {
     static bool attr_done[64] = {false};            // per device: the attribute belongs to the device's code object
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
@@ -287,7 +287,12 @@ hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
         attr_set = true;
     }
     constexpr bool LN = (EPI == EPI_RESID_LN_PRE || EPI == EPI_RESID_LN_POST);
-    const int grid = LN ? ln_grid_size(a.M >> 8, a.N >> 8) : (a.M >> 8) * (a.N >> 8);   // LN: whole row blocks per XCD
+    GemmArgs a = a0;
+    int grid = (a.M >> 8) * (a.N >> 8);
+    if (LN) {                                       // whole row blocks per XCD wherever the grid runs in rounds (host_logic.h)
+        a.ln_rowblock_map = ln_use_rowblock_map(a.M >> 8, a.N >> 8) ? 1 : 0;
+        if (a.ln_rowblock_map) grid = ln_grid_size(a.M >> 8, a.N >> 8);
+    }
     hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS, s, a);
     return hipGetLastError();
 }

@@ -17,7 +17,7 @@
 #define GITCAP_ABI_VERSION 1
 // (tools/build_diag.py redefines this to reach the experimental tile kernels of tools/experiments/)
 #ifndef GITCAP_DBG_GEMM_DISPATCH
-#define GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, s) ((tile) == 256 ? launch_gemm256(a, epi, s) : (tile) == 64 ? launch_gemm64(a, epi, s) : launch_gemm(a, epi, s))
+#define GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, s) ((tile) == 256 ? launch_gemm256(a, epi, s) : (tile) == 64 ? launch_gemm64(a, epi, s) : (tile) == 224 ? launch_gemm_mt(a, epi, 224, s) : (tile) == 257 ? launch_gemm_mt(a, epi, 256, s) : launch_gemm(a, epi, s))
 #endif
 
 // Speed-only switches (results do not depend on them: tests/test_parity_gpu.py).  Process-wide, set once from the
@@ -142,13 +142,26 @@ std::atomic<int> g_small_tiles{getenv("GITCAP_GEMM_SMALL_TILES") ? atoi(getenv("
 // 128x128-tile count below which the 64x64 kernel is used (GITCAP_GEMM_TINY_TILES=0 disables the switch)
 std::atomic<int> g_tiny_tiles{getenv("GITCAP_GEMM_TINY_TILES") ? atoi(getenv("GITCAP_GEMM_TINY_TILES")) : 200};     // measured crossover (tools/gemm_tiles_small.py): 180 -> 64x64, 228 -> 128x128
 
-// Tile kernel selection.  Few 256x256 tiles (small batches: one 6-frame clip is 5 x 3..12 tiles for 256 CUs) leave
-// most of the chip idle: below g_small_tiles tiles the 128x128 kernel (4x the workgroups, two per CU) is used
-// (B=1: 7.7 -> 6.8 ms per caption), and below g_tiny_tiles of THOSE the 64x64 kernel (16x, three per CU, 3-stage
-// ring: the single-clip launches).  All tile kernels produce bitwise identical results
-// (tests/test_kernels_gpu.py), so the choice only affects speed.
-hipError_t launch_gemm_auto(const GemmArgs& a, int epi, hipStream_t s) {
-    if (gemm256_ok(a) && (a.M >> 8) * (a.N >> 8) >= g_small_tiles) return launch_gemm256(a, epi, s);
+// 224-row tiles where they save rounds (GITCAP_NO_TILE224=1 / gitcap_dbg_config(4, 0): always 256 rows; host_logic.h: pick_tile_rows)
+std::atomic<bool> g_tile224{getenv("GITCAP_NO_TILE224") == nullptr};
+
+// Tile kernel selection.  `rows` = the valid rows of the launch; a.M comes in as rows padded to 256.  Few 256x256 tiles
+// (small batches: one 6-frame clip is 5 x 3..12 tiles for 256 CUs) leave most of the chip idle: below g_small_tiles
+// tiles the 128x128 kernel (4x the workgroups, two per CU) is used (B=1: 7.7 -> 6.8 ms per caption), and below
+// g_tiny_tiles of THOSE the 64x64 kernel (16x, three per CU, 3-stage ring: the single-clip launches).  Big launches
+// take 256(n) x 224(m) tiles where that turns partial rounds on the 256 CUs into full ones (the bench shape: every GEMM,
+// -12.5 % K-loop time).  All tile kernels produce bitwise identical results (tests/test_kernels_gpu.py), so the choice
+// only affects speed.
+hipError_t launch_gemm_auto(GemmArgs a, int epi, hipStream_t s, int rows) {
+    const bool ln = epi == EPI_RESID_LN_PRE || epi == EPI_RESID_LN_POST;
+    if (gemm256_ok(a) && (a.M >> 8) * (a.N >> 8) >= g_small_tiles) {
+        if (g_tile224 && rows > 0 && pick_tile_rows(rows, a.N, ln) == 224) {
+            a.M = (rows + 223) / 224 * 224;                       // the workspace holds 256 rows beyond the 256-padded rows
+            return launch_gemm_mt(a, epi, 224, s);
+        }
+        return launch_gemm256(a, epi, s);
+    }
+    if (ln) return hipErrorInvalidValue;
     if ((a.M & 63) == 0 && (a.N & 63) == 0 && ((a.M & 127) || (a.N & 127) || (a.M >> 7) * (a.N >> 7) < g_tiny_tiles))
         return launch_gemm64(a, epi, s);
     return launch_gemm(a, epi, s);
@@ -253,7 +266,7 @@ int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = Wb; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
     a.resid = resid; a.ldr = ldr;
-    HIP_OK(h, launch_gemm_auto(a, epi, s));
+    HIP_OK(h, launch_gemm_auto(a, epi, s, (int)h->prof_rows));
     return 0;
 }
 
@@ -272,6 +285,7 @@ int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const
     GemmArgs a{};
     a.A = A; a.lda = lda; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = xout; a.ldo = N; a.resid = resid; a.ldr = N;
     a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = eps; a.ln_out = ln_out; a.ld_ln = N; a.ln_stats = h->ln_stats; a.ln_cnt = h->ln_cnt;
+    a.ln_stats_rows = h->Mi;
     a.ln_add = addv; a.ln_add_div = add_div; a.ln_add_mod = add_mod; a.ln_out_f32 = ln_f32; a.ld_ln_f32 = N; a.valid_rows = rows;
     // ln_out may be the A operand itself (visual projection): a tile writes its rows only after every tile that reads
     // them has finished its K loop (that is what the exchange waits for) -- as long as both views have the same row stride
@@ -281,7 +295,7 @@ int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const
         HIP_OK(h, e);
         const double R = h->prof_rows;      // A + W + fp32 out + bf16 LayerNorm out (+ fp32 residual read)
         ProfScope ps(h, GITCAP_PROF_GEMM_LN, s, 2.0 * R * N * K, 2.0 * R * K + 2.0 * N * K + R * N * ((xout ? 4.0 : 0.0) + 2.0 + (ln_f32 ? 4.0 : 0.0) + (resid ? 4.0 : 0.0)));
-        HIP_OK(h, launch_gemm256(a, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s));
+        HIP_OK(h, launch_gemm_auto(a, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s, rows));
         return 0;
     }
     int rc;
@@ -495,8 +509,9 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     h->Kp = pad_to(3 * c.patch_size * c.patch_size, 64);
     h->Dv = c.enc_width; h->D = c.dec_width; h->V = c.vocab_size; h->Vp = pad_to(c.vocab_size, 16);
     h->Smax = c.max_frames * h->N;
-    h->Mi = pad_to(c.max_batch * h->Smax, 256);
-    h->Pp = pad_to(c.max_batch * c.max_frames * h->G * h->G, 256);
+    // + 256 rows: a launch on 224-row tiles covers up to 223 rows more than the valid ones and its LDS-DMA pieces read 16 further
+    h->Mi = pad_to(c.max_batch * h->Smax, 256) + 256;
+    h->Pp = pad_to(c.max_batch * c.max_frames * h->G * h->G, 256) + 256;
     h->R = c.max_batch * c.max_beams; h->Tmax = c.max_text_len;
     h->Mt = pad_to(h->R * h->Tmax, 16);
     const int Dm = std::max(h->Dv, h->D), Fm = std::max(c.enc_ffn, c.dec_ffn);
@@ -505,7 +520,7 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     rc = rc ? rc : ws_alloc(h, &h->x, Mi * Dm);
     rc = rc ? rc : ws_alloc(h, &h->tmp, Mi * h->D);
     rc = rc ? rc : ws_alloc(h, &h->ln_stats, Mi * 16);
-    rc = rc ? rc : ws_alloc(h, &h->ln_cnt, 2 * (Mi / 256 + 1));
+    rc = rc ? rc : ws_alloc(h, &h->ln_cnt, 2 * (Mi / 224 + 2));
     rc = rc ? rc : ws_alloc(h, &h->hb, Mi * Dm);
     rc = rc ? rc : ws_alloc(h, &h->qkv, Mi * 3 * h->Dv);
     rc = rc ? rc : ws_alloc(h, &h->ctx, Mi * Dm);
@@ -743,7 +758,7 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
         GemmArgs a{};
         a.A = h->patches; a.lda = h->Kp; a.W = Wb; a.bias = nullptr; a.M = Pp; a.N = Dv; a.K = h->Kp;
         a.out = h->x; a.ldo = Dv; a.pos = h->pos; a.tokens_per_frame = N; a.patches_per_frame = h->G * h->G; a.valid_rows = P;
-        HIP_OK(h, launch_gemm_auto(a, EPI_PATCH_F32, s));
+        HIP_OK(h, launch_gemm_auto(a, EPI_PATCH_F32, s, P));
     }
     HIP_OK(h, launch_cls_rows(h->x, h->cls, h->pos, nf, N, Dv, s));
     h->prof_rows = rows;
@@ -1003,7 +1018,7 @@ int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float
     a.A = (const bf16_t*)A; a.lda = K; a.W = (const bf16_t*)W; a.bias = bias; a.M = M; a.N = N; a.K = K;
     a.out = out; a.ldo = N; a.resid = resid; a.ldr = N;
     if (epi < 0 || epi > EPI_BIAS_F32) return GITCAP_ERR_ARG;
-    if (tile != 64 && tile != 128 && tile != 256) return GITCAP_ERR_ARG;
+    if (tile != 64 && tile != 128 && tile != 256 && tile != 224 && tile != 257) return GITCAP_ERR_ARG;
     hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, (hipStream_t)stream);
     return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
 }
@@ -1031,21 +1046,32 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
         if (tmp) { (void)hipStreamSynchronize(s); (void)hipFree(tmp); }
         return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
     }
-    if (M / 256 + 1 > cap) {
+    if (M / 224 + 2 > cap) {
         if (stats) { (void)hipFree(stats); (void)hipFree(cnt); }
-        cap = M / 256 + 1;
+        cap = M / 224 + 2;
         if (hipMalloc(&stats, (size_t)cap * 256 * 16 * sizeof(float2)) != hipSuccess || hipMalloc(&cnt, (size_t)cap * 8) != hipSuccess) return GITCAP_ERR_NOMEM;
         if (hipMemset(cnt, 0, (size_t)cap * 8) != hipSuccess) return GITCAP_ERR_HIP;
     }
     a.ln_g = gamma; a.ln_b = beta; a.ln_eps = eps; a.ln_out = (bf16_t*)out_bf16; a.ld_ln = N; a.ln_stats = stats; a.ln_cnt = cnt;
-    if (!gemm256_ln_ok(a) || (!post && !resid)) return GITCAP_ERR_ARG;
-    const hipError_t e = launch_gemm256(a, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s);
+    a.ln_stats_rows = cap * 224;
+    const int epi = post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE;
+    if (!post && !resid) return GITCAP_ERR_ARG;
+    hipError_t e;
+    if (fused == 1) {                               // the 256x256 kernel of gemm256.hip
+        if (!gemm256_ln_ok(a)) return GITCAP_ERR_ARG;
+        e = launch_gemm256(a, epi, s);
+    } else {                                        // fused = 224 / 257: gemm_mt.hip on 224- / 256-row tiles
+        const int tr = fused == 257 ? 256 : fused;
+        if (!gemm_mt_ln_ok(a, tr)) return GITCAP_ERR_ARG;
+        e = launch_gemm_mt(a, epi, tr, s);
+    }
     return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
 }
 
 // Speed-only switches at run time (the same ones the GITCAP_* environment variables set once per process): lets ONE process
 // check that results do not depend on them.  key 0: GEMM + LayerNorm epilogue on/off, 1: one/two-row prologue on/off,
-// 2: 256-tile threshold (GITCAP_GEMM_SMALL_TILES), 3: 128-tile threshold (GITCAP_GEMM_TINY_TILES).  Returns the old value.
+// 2: 256-tile threshold (GITCAP_GEMM_SMALL_TILES), 3: 128-tile threshold (GITCAP_GEMM_TINY_TILES), 4: 224-row tiles on/off.
+// Returns the old value.
 int gitcap_dbg_config(int key, int value) {
     int old = -1;
     switch (key) {
@@ -1053,6 +1079,7 @@ int gitcap_dbg_config(int key, int value) {
         case 1: old = g_row_prologue.exchange(value != 0); break;
         case 2: old = g_small_tiles.exchange(value); break;
         case 3: old = g_tiny_tiles.exchange(value); break;
+        case 4: old = g_tile224.exchange(value != 0); break;
         default: return GITCAP_ERR_ARG;
     }
     return old;

@@ -75,6 +75,16 @@ int main() {
                     if (tn) CHECK(seen[(size_t)tm * ntn + tn] == seen[(size_t)tm * ntn + tn - 1] + 8);   // same XCD, next in its sequence
                 }
         }
+    // tile height: the bench shape (18 912 rows) takes 224-row tiles for every GEMM width; exact multiples of 256 keep 256
+    CHECK(pick_tile_rows(18912, 768, false) == 224 && pick_tile_rows(18912, 2304, false) == 224 && pick_tile_rows(18912, 3072, false) == 224);
+    CHECK(pick_tile_rows(18912, 768, true) == 224 && !ln_use_rowblock_map(85, 3) && ln_use_rowblock_map(74, 3) && ln_use_rowblock_map(148, 3));
+    CHECK(pick_tile_rows(65536, 768, false) == 256 && pick_tile_rows(256, 768, false) == 256);
+    for (int rows = 1; rows < 70000; rows += 97)
+        for (int N : {768, 1024, 2304, 3072, 4096}) {
+            const int bm = pick_tile_rows(rows, N, N <= 1024);
+            CHECK(bm == 224 || bm == 256);
+            CHECK(tile_rounds_cost(rows, N >> 8, bm, N <= 1024) <= tile_rounds_cost(rows, N >> 8, 256, N <= 1024));
+        }
     CHECK(pad_to(18912, 256) == 18944 && pad_to(256, 256) == 256 && pad_to(1, 16) == 16);
     std::puts("host_asan_test ok");
     return 0;

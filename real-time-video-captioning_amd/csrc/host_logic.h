@@ -127,6 +127,10 @@ inline bool ticket_waitable(int ticket, int next_ticket, int nslot) {
 // workgroup: XCD x is handed a balanced contiguous range of WHOLE row blocks, their ntn tiles consecutive in its
 // sequence.  The grid is padded to 8 * ntn * ceil(nrb / 8); surplus workgroups (the last of every sequence) get no tile.
 GITCAP_HD inline int ln_grid_size(int nrb, int ntn) { return 8 * ntn * ((nrb + 7) >> 3); }
+// When to use that map.  A grid of more than 256 tiles runs in several rounds: the map is needed for progress.  A grid
+// that fits the chip is co-resident whatever the map; there the row-block map is used only if it still fits every XCD's 32
+// CUs (85 row blocks x 3 tiles = 255 workgroups do not: 11 blocks = 33 tiles on five XCDs), otherwise the plain XCD remap.
+inline bool ln_use_rowblock_map(int nrb, int ntn) { return nrb * ntn > 256 || ((nrb + 7) >> 3) * ntn <= 32; }
 GITCAP_HD inline bool ln_tile_of_block(int bid, int nrb, int ntn, int* tm, int* tn) {
     const int xcd = bid & 7, slot = bid >> 3;
     const int c = nrb >> 3, r = nrb & 7;
@@ -135,4 +139,18 @@ GITCAP_HD inline bool ln_tile_of_block(int bid, int nrb, int ntn, int* tm, int* 
     if (j >= cnt) return false;
     *tm = start + j; *tn = slot - j * ntn;
     return true;
+}
+
+// ---- tile height of a big-tile GEMM launch -----------------------------------------------------------------------------
+// One workgroup per CU, 256 CUs: a launch runs in whole rounds, so its K-loop time goes as rounds x tile rows.  224-row
+// tiles turn the bench shape's 0.87 / 2.6 / 3.47 rounds of 256-row tiles into 1 / 3 / 4 full rounds of 7/8 the work
+// (gemm_mt.hip).  Speed only: both heights give the same bits.
+inline long tile_rounds_cost(int rows, int ntn, int bm, bool ln) {
+    const int nrb = (rows + bm - 1) / bm, tiles = nrb * ntn;
+    long rounds = (tiles + 255) / 256;
+    if (ln && tiles > 256) rounds = (((nrb + 7) >> 3) * ntn + 31) / 32;      // whole row blocks per XCD, 32 CUs each
+    return rounds * bm;
+}
+inline int pick_tile_rows(int rows, int N, bool ln) {
+    return tile_rounds_cost(rows, N >> 8, 224, ln) < tile_rounds_cost(rows, N >> 8, 256, ln) ? 224 : 256;
 }

@@ -31,14 +31,21 @@ struct GemmArgs {
     const float* ln_add;          // nullable (PRE): LayerNorm output += ln_add[((row / ln_add_div) % ln_add_mod) * N + n]  (temporal embedding)
     int ln_add_div, ln_add_mod;
     float* ln_out_f32; int ld_ln_f32;   // nullable (PRE): fp32 copy of the LayerNorm output, rows < valid_rows only (caller's unpadded buffer)
-    float2* ln_stats;             // [M][16] per-segment (mean, M2) exchanged between the tiles of a row block
-    unsigned* ln_cnt;             // [M / 256][2] per row block {arrivals, generation}: zero before the first launch, self-resetting
+    float2* ln_stats;             // [ln_stats_rows][16] per-segment (mean, M2) exchanged between the tiles of a row block
+    unsigned* ln_cnt;             // [row blocks][2] per row block {arrivals, generation}: zero before the first launch, self-resetting
+    int ln_stats_rows;            // rows of ln_stats (>= M)
+    int ln_rowblock_map;          // set by the launcher: workgroup -> tile map hands every XCD whole row blocks (host_logic.h)
 };
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);      // 128x128 tile (any M%128, N%128)
 hipError_t launch_gemm64(const GemmArgs& a, int epi, hipStream_t s);    // 64x64 tile, 3-stage ring (few-hundred-row launches)
 bool gemm256_ok(const GemmArgs& a);
 hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);   // 256x256 tile, 8-wave ping-pong
 bool gemm256_ln_ok(const GemmArgs& a);                                   // shape the EPI_RESID_LN_* epilogues accept
+// 256(n) x tile_rows(m) tile, tile_rows = 224 or 256 (gemm_mt.hip): M % tile_rows == 0; with 224 the A buffer must be readable
+// 16 rows past M.  Same bits as every other tile kernel.
+bool gemm_mt_ok(const GemmArgs& a, int tile_rows);
+bool gemm_mt_ln_ok(const GemmArgs& a, int tile_rows);
+hipError_t launch_gemm_mt(const GemmArgs& a, int epi, int tile_rows, hipStream_t s);
 
 // ---- skinny GEMMs (text rows; M = a few 16-row tiles): weight streaming, one wave per tile ----
 enum SkinnyEpi { SK_BIAS_BF16 = 0, SK_BIAS_GELU_BF16 = 1, SK_BIAS_RELU_BF16 = 2, SK_BIAS_F32 = 3 };
