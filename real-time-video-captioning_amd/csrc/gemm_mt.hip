@@ -197,12 +197,21 @@ __device__ __forceinline__ void epilogue_tile_ln(const GemmArgs& a, const f32x4 
         }
     }
     __syncthreads();
-    {   // the wave's WR rows x 128 B of statistics: 2*MT coalesced 16-byte loads per lane into the wave's staging region
+    {   // the wave's WR rows x 128 B of statistics: 2*MT coalesced 16-byte loads per lane into the wave's staging region.
+        // Row pitch 144 B (conflict-free 16-byte stores and reads) while WR rows fit the region (MT = 7: 16128 B); with 128
+        // rows the pitch is 136 B (17408 B = the whole region; 8-byte aligned rows, so 8-byte stores).
+        constexpr int PITCH = MT == 8 ? 136 : 144;
+        static_assert(16 * MT * PITCH <= EPI_REGION, "statistics staging must fit the wave's region");
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
             const int row = i * 8 + (lane >> 3), ch = lane & 7;
             const u32x4_mt v = __builtin_amdgcn_raw_buffer_load_b128(srs, ((mw + row) * 16 + ch * 2) * 8, 0, 16);
-            *(u32x4_mt*)(ep + row * 144 + ch * 16) = v;                  // 144-byte row pitch: conflict-free 16-byte reads below
+            if (MT == 8) {
+                *(uint2*)(ep + row * PITCH + ch * 16) = make_uint2(v[0], v[1]);
+                *(uint2*)(ep + row * PITCH + ch * 16 + 8) = make_uint2(v[2], v[3]);
+            } else {
+                *(u32x4_mt*)(ep + row * PITCH + ch * 16) = v;
+            }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
@@ -210,7 +219,7 @@ __device__ __forceinline__ void epilogue_tile_ln(const GemmArgs& a, const f32x4 
         for (int p = 0; p < 2; ++p) {
             const int row = p * 64 + lane;
             if (row < WR) {
-                const float2* src = (const float2*)(ep + row * 144);
+                const float2* src = (const float2*)(ep + row * PITCH);
                 float mean, rstd;
                 if (a.N == 768) ln_merge<12>([&](int q) { return src[q]; }, a.ln_eps, mean, rstd);
                 else ln_merge<16>([&](int q) { return src[q]; }, a.ln_eps, mean, rstd);

@@ -168,7 +168,7 @@ def test_one_and_two_row_steps_equal_teacher_forced(captioner_cls, size, B):
 
 
 def test_results_do_not_depend_on_speed_switches(captioner_cls):
-    """Tile choice (256 / 128 / 64), the GEMM + LayerNorm epilogue and the one/two-row prologue are speed decisions taken from
+    """Tile choice (256 x 256 / 256 x 224 / 128 / 64), the GEMM + LayerNorm epilogue and the one/two-row prologue are speed decisions taken from
     the batch size: flipping each of them at run time (gitcap_dbg_config) must not change a bit of the visual features, the
     teacher-forced logits or the captions -- at GIT-base size, for a batch of 8 clips (256-tile kernels) and a single clip."""
     from gitcap import _lib
@@ -184,7 +184,7 @@ def test_results_do_not_depend_on_speed_switches(captioner_cls):
         return vis.clone(), ids.clone(), m.forward_decoder(ids[:, :-1], vis).clone()
     base8, base1 = run(8), run(1)
     assert torch.equal(base1[1], base8[1][:1]) and torch.equal(base1[0], base8[0][:1])
-    settings = [(0, 0), (1, 0), (2, 1 << 30), (3, 0), (3, 1 << 30), (2, 1)]   # (key, value); (2, 1): 256-tile kernels even for one clip
+    settings = [(0, 0), (1, 0), (2, 1 << 30), (3, 0), (3, 1 << 30), (2, 1), (4, 0)]   # (key, value); (2, 1): 256-tile kernels even for one clip; (4, 0): no 224-row tiles
     for key, value in settings:
         old = lib.gitcap_dbg_config(key, value)
         assert old >= 0
