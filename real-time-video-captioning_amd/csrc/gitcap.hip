@@ -24,7 +24,7 @@
 // environment; gitcap_dbg_config (a test hook) may flip them at run time, so they are atomics: an entry point running on
 // another thread reads a consistent value at each use and either value gives the same bits.
 // g_row_prologue is shared with student.hip.
-std::atomic<bool> g_row_prologue{getenv("GITCAP_NO_ROW_PROLOGUE") == nullptr};
+std::atomic<bool> g_row_prologue{!env_flag("GITCAP_NO_ROW_PROLOGUE")};
 
 namespace {
 
@@ -119,6 +119,7 @@ struct gitcap {
     hipStream_t txt_streams[NSLOT] = {nullptr, nullptr, nullptr, nullptr};   // owned; slot i decodes on txt_streams[i % n_txt]
     int n_txt = NSLOT;
     double prof_rows = 0;   // valid rows of the GEMMs being launched (set by the callers of gemm())
+    bool pipelined = false; // the launches being issued belong to a gitcap_greedy_submit (other batches share the chip)
 
     // instrumentation (bench.py): HIP-event brackets per kernel class, on the launch stream
     bool prof_on = false;
@@ -142,8 +143,14 @@ std::atomic<int> g_small_tiles{getenv("GITCAP_GEMM_SMALL_TILES") ? atoi(getenv("
 // 128x128-tile count below which the 64x64 kernel is used (GITCAP_GEMM_TINY_TILES=0 disables the switch)
 std::atomic<int> g_tiny_tiles{getenv("GITCAP_GEMM_TINY_TILES") ? atoi(getenv("GITCAP_GEMM_TINY_TILES")) : 200};     // measured crossover (tools/gemm_tiles_small.py): 180 -> 64x64, 228 -> 128x128
 
-// 224-row tiles where they save rounds (GITCAP_NO_TILE224=1 / gitcap_dbg_config(4, 0): always 256 rows; host_logic.h: pick_tile_rows)
-std::atomic<bool> g_tile224{getenv("GITCAP_NO_TILE224") == nullptr};
+// 224-row tiles where they save rounds (host_logic.h: pick_tile_rows).  GITCAP_NO_TILE224=1 / gitcap_dbg_config(4, 0): never.
+// They are a LATENCY lever: a synchronous call (one batch alone on the chip) gains 1.4 % at the bench shape, but in the
+// pipeline the CUs a 256-row launch leaves idle (34 of 256 at N = 768, the partial last round of the wider GEMMs) are
+// what the token loops of the batches in flight run on: with 224-row tiles everywhere the pipelined bench LOSES 4 %
+// (1670 vs 1742 captions/s, same box).  So submissions (gitcap_greedy_submit) keep 256-row tiles unless
+// GITCAP_TILE224_PIPELINED is set (1: every big launch, 2: only launches of several rounds; experiment switch).
+std::atomic<bool> g_tile224{!env_flag("GITCAP_NO_TILE224")};
+const int g_tile224_pipe = getenv("GITCAP_TILE224_PIPELINED") ? atoi(getenv("GITCAP_TILE224_PIPELINED")) : 0;
 
 // Tile kernel selection.  `rows` = the valid rows of the launch; a.M comes in as rows padded to 256.  Few 256x256 tiles
 // (small batches: one 6-frame clip is 5 x 3..12 tiles for 256 CUs) leave most of the chip idle: below g_small_tiles
@@ -152,10 +159,11 @@ std::atomic<bool> g_tile224{getenv("GITCAP_NO_TILE224") == nullptr};
 // take 256(n) x 224(m) tiles where that turns partial rounds on the 256 CUs into full ones (the bench shape: every GEMM,
 // -12.5 % K-loop time).  All tile kernels produce bitwise identical results (tests/test_kernels_gpu.py), so the choice
 // only affects speed.
-hipError_t launch_gemm_auto(GemmArgs a, int epi, hipStream_t s, int rows) {
+hipError_t launch_gemm_auto(GemmArgs a, int epi, hipStream_t s, int rows, bool pipelined) {
     const bool ln = epi == EPI_RESID_LN_PRE || epi == EPI_RESID_LN_POST;
     if (gemm256_ok(a) && (a.M >> 8) * (a.N >> 8) >= g_small_tiles) {
-        if (g_tile224 && rows > 0 && pick_tile_rows(rows, a.N, ln) == 224) {
+        const bool allow224 = g_tile224 && (!pipelined || g_tile224_pipe == 1 || (g_tile224_pipe == 2 && (a.M >> 8) * (a.N >> 8) > 256));
+        if (allow224 && rows > 0 && pick_tile_rows(rows, a.N, ln) == 224) {
             a.M = (rows + 223) / 224 * 224;                       // the workspace holds 256 rows beyond the 256-padded rows
             return launch_gemm_mt(a, epi, 224, s);
         }
@@ -266,7 +274,7 @@ int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = Wb; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
     a.resid = resid; a.ldr = ldr;
-    HIP_OK(h, launch_gemm_auto(a, epi, s, (int)h->prof_rows));
+    HIP_OK(h, launch_gemm_auto(a, epi, s, (int)h->prof_rows, h->pipelined));
     return 0;
 }
 
@@ -276,7 +284,7 @@ int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef
 // Large launches run both inside the 256x256 kernel (EPI_RESID_LN_*: the tiles of a row block exchange segment
 // statistics); small ones the 128x128 kernel + the row kernel.  Both give the same bits (ln_canon.h).
 // GITCAP_NO_GEMM_LN=1 (diagnosis / A-B only) keeps every LayerNorm a launch of its own.
-std::atomic<bool> g_fuse_ln{getenv("GITCAP_NO_GEMM_LN") == nullptr};
+std::atomic<bool> g_fuse_ln{!env_flag("GITCAP_NO_GEMM_LN")};
 
 int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const WRef& W, const float* bias, int M, int N,
             int K, float* xout, const float* resid, const float* ln_g, const float* ln_b, float eps, int rows,
@@ -295,7 +303,7 @@ int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const
         HIP_OK(h, e);
         const double R = h->prof_rows;      // A + W + fp32 out + bf16 LayerNorm out (+ fp32 residual read)
         ProfScope ps(h, GITCAP_PROF_GEMM_LN, s, 2.0 * R * N * K, 2.0 * R * K + 2.0 * N * K + R * N * ((xout ? 4.0 : 0.0) + 2.0 + (ln_f32 ? 4.0 : 0.0) + (resid ? 4.0 : 0.0)));
-        HIP_OK(h, launch_gemm_auto(a, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s, rows));
+        HIP_OK(h, launch_gemm_auto(a, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s, rows, h->pipelined));
         return 0;
     }
     int rc;
@@ -758,7 +766,7 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
         GemmArgs a{};
         a.A = h->patches; a.lda = h->Kp; a.W = Wb; a.bias = nullptr; a.M = Pp; a.N = Dv; a.K = h->Kp;
         a.out = h->x; a.ldo = Dv; a.pos = h->pos; a.tokens_per_frame = N; a.patches_per_frame = h->G * h->G; a.valid_rows = P;
-        HIP_OK(h, launch_gemm_auto(a, EPI_PATCH_F32, s, P));
+        HIP_OK(h, launch_gemm_auto(a, EPI_PATCH_F32, s, P, h->pipelined));
     }
     HIP_OK(h, launch_cls_rows(h->x, h->cls, h->pos, nf, N, Dv, s));
     h->prof_rows = rows;
@@ -899,7 +907,10 @@ int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max
     HIP_OK(h, hipStreamWaitEvent(h->s_enc, sl.ev_in, 0));
     // ... and once the previous user of this slot's image K/V (two submissions ago) has finished decoding
     if (sl.used) HIP_OK(h, hipStreamWaitEvent(h->s_enc, sl.ev_dec, 0));
-    if ((rc = encode_impl(h, FrameSrc{frames, nullptr, 0, 0}, B, F, nullptr, h->s_enc))) return rc;
+    h->pipelined = true;
+    rc = encode_impl(h, FrameSrc{frames, nullptr, 0, 0}, B, F, nullptr, h->s_enc);
+    h->pipelined = false;
+    if (rc) return rc;
     HIP_OK(h, hipEventRecord(sl.ev_enc, h->s_enc));
     HIP_OK(h, hipStreamWaitEvent(sl.s_txt, sl.ev_enc, 0));
     if ((rc = greedy_text_loop(h, B, max_len, stop, ids_out, steps_out, sl.s_txt))) return rc;

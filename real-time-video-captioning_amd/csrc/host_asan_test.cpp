@@ -77,8 +77,8 @@ int main() {
         }
     // tile height: the bench shape (18 912 rows) takes 224-row tiles for every GEMM width; exact multiples of 256 keep 256
     CHECK(pick_tile_rows(18912, 768, false) == 224 && pick_tile_rows(18912, 2304, false) == 224 && pick_tile_rows(18912, 3072, false) == 224);
-    CHECK(pick_tile_rows(18912, 768, true) == 224 && !ln_use_rowblock_map(85, 3) && ln_use_rowblock_map(74, 3) && ln_use_rowblock_map(148, 3));
-    CHECK(pick_tile_rows(65536, 768, false) == 256 && pick_tile_rows(256, 768, false) == 256);
+    CHECK(pick_tile_rows(18912, 768, true) == 224 && !ln_use_rowblock_map(85, 3) && !ln_use_rowblock_map(74, 3) && ln_use_rowblock_map(148, 3));
+    CHECK(pick_tile_rows(65536, 768, false) == 256 && pick_tile_rows(65536, 3072, false) == 256);
     for (int rows = 1; rows < 70000; rows += 97)
         for (int N : {768, 1024, 2304, 3072, 4096}) {
             const int bm = pick_tile_rows(rows, N, N <= 1024);

@@ -5,6 +5,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -19,6 +20,12 @@
 #endif
 
 inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+// an on/off environment switch: set and neither empty nor "0"
+inline bool env_flag(const char* name) {
+    const char* v = getenv(name);
+    return v && v[0] && !(v[0] == '0' && v[1] == 0);
+}
 
 inline uint16_t host_f2bf(float f) {    // round-to-nearest-even, NaN stays NaN
     uint32_t u;
@@ -127,10 +134,11 @@ inline bool ticket_waitable(int ticket, int next_ticket, int nslot) {
 // workgroup: XCD x is handed a balanced contiguous range of WHOLE row blocks, their ntn tiles consecutive in its
 // sequence.  The grid is padded to 8 * ntn * ceil(nrb / 8); surplus workgroups (the last of every sequence) get no tile.
 GITCAP_HD inline int ln_grid_size(int nrb, int ntn) { return 8 * ntn * ((nrb + 7) >> 3); }
-// When to use that map.  A grid of more than 256 tiles runs in several rounds: the map is needed for progress.  A grid
-// that fits the chip is co-resident whatever the map; there the row-block map is used only if it still fits every XCD's 32
-// CUs (85 row blocks x 3 tiles = 255 workgroups do not: 11 blocks = 33 tiles on five XCDs), otherwise the plain XCD remap.
-inline bool ln_use_rowblock_map(int nrb, int ntn) { return nrb * ntn > 256 || ((nrb + 7) >> 3) * ntn <= 32; }
+// When to use that map: only where it is needed for progress, i.e. on grids of more than 256 tiles, which run in several
+// rounds.  A grid that fits the chip is co-resident whatever the map and keeps the plain XCD remap, whose even spread
+// (222 tiles: 28 / 27 per XCD) leaves every XCD free CUs for the token-loop kernels of the other streams: handing XCDs
+// whole row blocks there (30 / 27) cost the pipelined bench 5 % (1651 vs 1742 captions/s, same box, round 3).
+inline bool ln_use_rowblock_map(int nrb, int ntn) { return nrb * ntn > 256; }
 GITCAP_HD inline bool ln_tile_of_block(int bid, int nrb, int ntn, int* tm, int* tn) {
     const int xcd = bid & 7, slot = bid >> 3;
     const int c = nrb >> 3, r = nrb & 7;

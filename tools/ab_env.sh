@@ -1,8 +1,12 @@
-# A/B of one environment switch of libgitcap: bash tools/ab_env.sh VAR  (runs bench.py pipelined + --serial with VAR unset, then VAR=1)
-V=$1
-for mode in off on; do
-  if [ $mode = on ]; then export $V=1; else unset $V; fi
-  echo "== $V $mode"
-  timeout -k 10 200 python bench.py 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('pipelined', d['value'], d['ms_per_step'], d['roofline']['frac'])" || exit 1
-  timeout -k 10 200 python bench.py --serial 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('serial', d['value'], d['ms_per_step'])" || exit 1
+#!/bin/bash
+# A/B of environment switches of libgitcap in bench.py, interleaved, same box:  tools/ab_env.sh "VAR=1" "VAR=1 OTHER=1" ...
+# Each configuration (plus the empty one) runs pipelined and --serial, ROUNDS times, interleaved.
+ROUNDS=${ROUNDS:-2}
+for r in $(seq $ROUNDS); do
+  for cfg in "" "$@"; do
+    for mode in "" "--serial"; do
+      out=$(env $cfg python bench.py --no-cpu-baseline --plain $mode 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['p50_latency_ms'])")
+      echo "round $r  [${cfg:-default}] ${mode:-pipelined}: $out"
+    done
+  done
 done
