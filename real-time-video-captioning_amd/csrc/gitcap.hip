@@ -108,7 +108,6 @@ struct gitcap {
         float *xs = nullptr, *xs2 = nullptr, *slabs = nullptr, *part = nullptr, *amax_val = nullptr; int* amax_idx = nullptr;
         unsigned* row_cnt = nullptr;
         bf16_t *xsb = nullptr, *fs = nullptr, *kv_txt = nullptr, *kv_txt2 = nullptr;
-        int64_t* g_ids = nullptr; int32_t* g_steps = nullptr;     // the captured token loop's own ids [R][Tmax + 1] / step count
         int B = 0, S = 0; bool have = false, used = false;
         hipEvent_t ev_in = nullptr, ev_enc = nullptr, ev_dec = nullptr;
         hipStream_t s_txt = nullptr;
@@ -121,10 +120,6 @@ struct gitcap {
     int n_txt = NSLOT;
     double prof_rows = 0;   // valid rows of the GEMMs being launched (set by the callers of gemm())
     bool pipelined = false; // the launches being issued belong to a gitcap_greedy_submit (other batches share the chip)
-    // captured greedy token loops (greedy_text_loop)
-    struct LoopGraph { int slot, B, S, max_len, stop; bool rows_pro; const void* kvt; hipGraphExec_t exec; };
-    std::vector<LoopGraph> loop_graphs;
-    hipStream_t cap_stream = nullptr;
 
     // instrumentation (bench.py): HIP-event brackets per kernel class, on the launch stream
     bool prof_on = false;
@@ -545,8 +540,6 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
         if (i == 0) sl.kv_img = h->kv_img;
         else rc = rc ? rc : ws_alloc(h, &sl.kv_img, (size_t)c.dec_layers * Mi * 3 * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.sep_cnt, (size_t)h->Tmax + 1);
-        rc = rc ? rc : ws_alloc(h, &sl.g_ids, (size_t)h->R * (h->Tmax + 1));
-        rc = rc ? rc : ws_alloc(h, &sl.g_steps, (size_t)4);
         rc = rc ? rc : ws_alloc(h, &sl.xs, Mt * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.xs2, 2 * h->D);            // second copy of the residual rows for the one/two-row form
         rc = rc ? rc : ws_alloc(h, &sl.slabs, (size_t)16 * Mt * h->D);
@@ -620,8 +613,6 @@ void gitcap_destroy(gitcap_t* h) {
         if (sl.ev_enc) (void)hipEventDestroy(sl.ev_enc);
         if (sl.ev_dec) (void)hipEventDestroy(sl.ev_dec);
     }
-    for (auto& g : h->loop_graphs) (void)hipGraphExecDestroy(g.exec);
-    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     for (auto& t : h->txt_streams)
         if (t) (void)hipStreamDestroy(t);
     if (h->s_enc) (void)hipStreamDestroy(h->s_enc);
@@ -848,51 +839,18 @@ int gitcap_text_forward(gitcap_t* h, const int64_t* ids, int ld_ids, int rows, i
                         (hipStream_t)stream);
 }
 
-// The greedy token loop is a chain of max_len x ~32 dependent launches, each a few microseconds: issued one by one the
-// gaps between them are set by the host (2.4 us per boundary against 1.6 us for a replayed hipGraph, tools/probe/chain.hip).
-// The loop is therefore captured once per (slot, clips, image keys, max_len, stop rule) into a hipGraph that works on the
-// slot's own ids buffer, and replayed; the caller's buffers are filled by two small copies behind it.  Same kernels, same
-// arguments, same results (tests/test_parity_gpu.py flips the switch).  GITCAP_NO_LOOP_GRAPH=1 / gitcap_dbg_config(5, 0):
-// launch kernel by kernel.  Not used while profiling brackets or the hidden-state export are on (they add stream operations).
-std::atomic<bool> g_loop_graph{!env_flag("GITCAP_NO_LOOP_GRAPH")};
-
 static int greedy_text_loop(gitcap* h, int B, int max_len, int stop, int64_t* ids_out, int32_t* steps_out, hipStream_t s) {
     const int ld = max_len + 1;
-    auto enqueue = [&](hipStream_t q, int64_t* ids, int32_t* steps) -> int {
-        // CLS start tokens [B,1] (model.py:171)
-        HIP_OK(h, launch_fill_i64(ids, ld, B, h->c.cls_token_id, q));
-        HIP_OK(h, hipMemsetAsync(h->sep_cnt, 0, ((size_t)h->Tmax + 1) * 4, q));
-        for (int t = 0; t < max_len; ++t) {
-            // forward on the sequence so far, argmax of the last position, append (model.py:173-182)
-            const int rc = text_forward(h, ids + t, ld, B, 1, t, 1, nullptr, 0, ids + t + 1, ld, h->sep_cnt, t, q);
-            if (rc) return rc;
-        }
-        if (steps) HIP_OK(h, launch_finish_steps(h->sep_cnt, B, max_len, stop, steps, q));
-        return 0;
-    };
-    if (!g_loop_graph || h->prof_on || h->want_hidden) return enqueue(s, ids_out, steps_out);
-    gitcap::Slot& sl = h->slots[h->cur_slot];
-    const bool rows_pro = g_row_prologue;
-    hipGraphExec_t exec = nullptr;
-    for (auto& g : h->loop_graphs)
-        if (g.slot == h->cur_slot && g.B == B && g.S == h->cur_S && g.max_len == max_len && g.stop == stop && g.rows_pro == rows_pro &&
-            g.kvt == (const void*)h->kv_txt) exec = g.exec;
-    if (!exec) {
-        hipGraph_t graph = nullptr;
-        if (!h->cap_stream) HIP_OK(h, hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
-        HIP_OK(h, hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-        const int rc = enqueue(h->cap_stream, sl.g_ids, sl.g_steps);
-        hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
-        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-        HIP_OK(h, e);
-        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        HIP_OK(h, e);
-        h->loop_graphs.push_back({h->cur_slot, B, h->cur_S, max_len, stop, rows_pro, (const void*)h->kv_txt, exec});
+    int rc;
+    // CLS start tokens [B,1] (model.py:171)
+    HIP_OK(h, launch_fill_i64(ids_out, ld, B, h->c.cls_token_id, s));
+    HIP_OK(h, hipMemsetAsync(h->sep_cnt, 0, ((size_t)h->Tmax + 1) * 4, s));
+    for (int t = 0; t < max_len; ++t) {
+        // forward on the sequence so far, argmax of the last position, append (model.py:173-182)
+        rc = text_forward(h, ids_out + t, ld, B, 1, t, 1, nullptr, 0, ids_out + t + 1, ld, h->sep_cnt, t, s);
+        if (rc) return rc;
     }
-    HIP_OK(h, hipGraphLaunch(exec, s));
-    HIP_OK(h, hipMemcpyAsync(ids_out, sl.g_ids, (size_t)B * ld * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
-    if (steps_out) HIP_OK(h, hipMemcpyAsync(steps_out, sl.g_steps, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    if (steps_out) HIP_OK(h, launch_finish_steps(h->sep_cnt, B, max_len, stop, steps_out, s));
     return 0;
 }
 
@@ -1123,8 +1081,7 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
 
 // Speed-only switches at run time (the same ones the GITCAP_* environment variables set once per process): lets ONE process
 // check that results do not depend on them.  key 0: GEMM + LayerNorm epilogue on/off, 1: one/two-row prologue on/off,
-// 2: 256-tile threshold (GITCAP_GEMM_SMALL_TILES), 3: 128-tile threshold (GITCAP_GEMM_TINY_TILES), 4: 224-row tiles on/off,
-// 5: captured (hipGraph) greedy token loop on/off.
+// 2: 256-tile threshold (GITCAP_GEMM_SMALL_TILES), 3: 128-tile threshold (GITCAP_GEMM_TINY_TILES), 4: 224-row tiles on/off.
 // Returns the old value.
 int gitcap_dbg_config(int key, int value) {
     int old = -1;
@@ -1134,7 +1091,6 @@ int gitcap_dbg_config(int key, int value) {
         case 2: old = g_small_tiles.exchange(value); break;
         case 3: old = g_tiny_tiles.exchange(value); break;
         case 4: old = g_tile224.exchange(value != 0); break;
-        case 5: old = g_loop_graph.exchange(value != 0); break;
         default: return GITCAP_ERR_ARG;
     }
     return old;
