@@ -208,19 +208,26 @@ int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launche
 /* Kernel-level test hooks (tests/test_kernels_gpu.py, tools/gemm_bench.py): run ONE kernel on
  * caller-owned device buffers.  gemm: out[m][n] = sum_k A[m][k]*W[n][k] (+epilogue `epi` of
  * csrc/kernels.h: 0 bias->bf16, 1 bias+QuickGELU->bf16, 2 bias+GELU->bf16, 3 bias+resid->f32,
- * 4 bias->f32); A [M][K] bf16, W [N][K] bf16; tile = 64, 128 or 256 (the three product tile kernels: M, N multiples of the tile). */
+ * 4 bias->f32); A [M][K] bf16, W [N][K] bf16; tile = 64, 128 or 256 (square tiles: M, N multiples of the tile), 224 = the 256(n) x 224(m)
+ * kernel (M % 224 == 0, A readable 16 rows past M), 257 = that kernel on 256 rows. */
 int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float* resid, void* out,
                     int M, int N, int K, int epi, int tile, void* stream);
+/* The same product with e4m3 weight storage read directly by the big-tile kernel (csrc/gemm_mt.hip): W8 = OCP e4m3 bytes [N][K],
+ * wscale [N] = one power-of-two scale per weight row; tile_rows = 224 or 256, M % tile_rows == 0 (224: A readable 16 rows past M).
+ * Bitwise equal to gitcap_dbg_gemm on the bf16 weights W8 * wscale. */
+int gitcap_dbg_gemm_wq(const void* A, const void* W8, const float* wscale, const float* bias, const float* resid, void* out,
+                        int M, int N, int K, int epi, int tile_rows, void* stream);
 /* GEMM + bias [+ resid] followed by LayerNorm of the output rows (N = 768 or 1024).  post = 0: out_f32 = x = A W^T + bias +
  * resid, out_bf16 = LN(x) (pre-LN block); post = 1: out_f32 = out_bf16 = LN(x), resid may be NULL (post-LN block).
- * fused = 1: inside the 256x256 kernel (the tiles of a 256-row block exchange segment statistics); fused = 0: the `tile`
- * kernel, then the row kernel.  Both produce the same bits (csrc/ln_canon.h). */
+ * fused = 1: inside the 256x256 kernel (the tiles of a 256-row block exchange segment statistics); fused = 224 / 257: inside the
+ * 256 x 224 kernel / that kernel on 256 rows (M a multiple of the tile rows); fused = 0: the `tile` kernel, then the row kernel.
+ * All produce the same bits (csrc/ln_canon.h). */
 int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const float* resid, const float* gamma,
                        const float* beta, float eps, float* out_f32, void* out_bf16, int M, int N, int K, int post,
                        int fused, int tile, void* stream);
 /* Speed-only switches at run time (what the GITCAP_* environment variables set once per process; INTEGRATION.md par. 9), so that
  * one process can check that results do not depend on them.  key 0: GEMM + LayerNorm epilogue on/off; 1: one/two-row prologue
- * on/off; 2: 256x256-tile threshold; 3: 128x128-tile threshold.  Returns the previous value (< 0: bad key).  The switches are process-wide atomics: a call on another thread sees either value,
+ * on/off; 2: 256x256-tile threshold; 3: 128x128-tile threshold; 4: 224-row tiles for synchronous calls on/off.  Returns the previous value (< 0: bad key).  The switches are process-wide atomics: a call on another thread sees either value,
  * and either value gives the same bits. */
 int gitcap_dbg_config(int key, int value);
 /* attn_full: qkv [G*S][3*H*64] bf16 -> ctx [G*S][H*64] bf16 */

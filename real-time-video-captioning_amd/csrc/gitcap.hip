@@ -152,29 +152,6 @@ std::atomic<int> g_tiny_tiles{getenv("GITCAP_GEMM_TINY_TILES") ? atoi(getenv("GI
 std::atomic<bool> g_tile224{!env_flag("GITCAP_NO_TILE224")};
 const int g_tile224_pipe = getenv("GITCAP_TILE224_PIPELINED") ? atoi(getenv("GITCAP_TILE224_PIPELINED")) : 0;
 
-// Tile kernel selection.  `rows` = the valid rows of the launch; a.M comes in as rows padded to 256.  Few 256x256 tiles
-// (small batches: one 6-frame clip is 5 x 3..12 tiles for 256 CUs) leave most of the chip idle: below g_small_tiles
-// tiles the 128x128 kernel (4x the workgroups, two per CU) is used (B=1: 7.7 -> 6.8 ms per caption), and below
-// g_tiny_tiles of THOSE the 64x64 kernel (16x, three per CU, 3-stage ring: the single-clip launches).  Big launches
-// take 256(n) x 224(m) tiles where that turns partial rounds on the 256 CUs into full ones (the bench shape: every GEMM,
-// -12.5 % K-loop time).  All tile kernels produce bitwise identical results (tests/test_kernels_gpu.py), so the choice
-// only affects speed.
-hipError_t launch_gemm_auto(GemmArgs a, int epi, hipStream_t s, int rows, bool pipelined) {
-    const bool ln = epi == EPI_RESID_LN_PRE || epi == EPI_RESID_LN_POST;
-    if (gemm256_ok(a) && (a.M >> 8) * (a.N >> 8) >= g_small_tiles) {
-        const bool allow224 = g_tile224 && (!pipelined || g_tile224_pipe == 1 || (g_tile224_pipe == 2 && (a.M >> 8) * (a.N >> 8) > 256));
-        if (allow224 && rows > 0 && pick_tile_rows(rows, a.N, ln) == 224) {
-            a.M = (rows + 223) / 224 * 224;                       // the workspace holds 256 rows beyond the 256-padded rows
-            return launch_gemm_mt(a, epi, 224, s);
-        }
-        return launch_gemm256(a, epi, s);
-    }
-    if (ln) return hipErrorInvalidValue;
-    if ((a.M & 63) == 0 && (a.N & 63) == 0 && ((a.M & 127) || (a.N & 127) || (a.M >> 7) * (a.N >> 7) < g_tiny_tiles))
-        return launch_gemm64(a, epi, s);
-    return launch_gemm(a, epi, s);
-}
-
 int fail(const gitcap* h, int code, const std::string& msg) {
     if (h) h->err = msg; else g_create_err = msg;
     return code;
@@ -253,28 +230,48 @@ int ln(gitcap* h, hipStream_t s, const float* x, int ldx, const float* g, const 
     return 0;
 }
 
-// e4m3 storage: the big-tile GEMMs read a weight panel through the bf16 staging buffer (expanded right before the
-// launch, on the same stream: the panel is a few MB and stays in L2 / the Infinity Cache; HBM sees the e4m3 bytes)
-const bf16_t* stage_weight(gitcap* h, hipStream_t s, const WRef& W, int N, int K, hipError_t* e) {
-    *e = hipSuccess;
-    if (!W.scale) return (const bf16_t*)W.p;
-    *e = launch_dequant_fp8((const unsigned char*)W.p, W.scale, h->wstage, pad_to(N, 16), K, s);
-    return h->wstage;
+// Tile kernel selection.  `rows` = the valid rows of the launch; a.M comes in as rows padded to 256.  Few 256x256 tiles
+// (small batches: one 6-frame clip is 5 x 3..12 tiles for 256 CUs) leave most of the chip idle: below g_small_tiles
+// tiles the 128x128 kernel (4x the workgroups, two per CU) is used (B=1: 7.7 -> 6.8 ms per caption), and below
+// g_tiny_tiles of THOSE the 64x64 kernel (16x, three per CU, 3-stage ring: the single-clip launches).  Big launches
+// take 256(n) x 224(m) tiles where that turns partial rounds on the 256 CUs into full ones (the bench shape: every GEMM,
+// -12.5 % K-loop time).  All tile kernels produce bitwise identical results (tests/test_kernels_gpu.py), so the choice
+// only affects speed.
+// Weights: bf16, or e4m3 bytes + row scales (W.scale != nullptr).  The big-tile kernel of gemm_mt.hip reads e4m3 panels
+// directly (LDS-DMA of the bytes, expansion on the fragment read, row scale on the accumulator: no staging launch); the
+// small-tile kernels read them through the bf16 staging buffer, expanded right before the launch on the same stream (the
+// panel is a few MB and stays in L2 / the Infinity Cache; HBM sees the e4m3 bytes).
+hipError_t launch_gemm_auto(gitcap* h, GemmArgs a, const WRef& W, int epi, hipStream_t s, int rows) {
+    const bool ln = epi == EPI_RESID_LN_PRE || epi == EPI_RESID_LN_POST;
+    a.W = (const bf16_t*)W.p; a.wscale = nullptr;
+    if (gemm256_ok(a) && (a.M >> 8) * (a.N >> 8) >= g_small_tiles) {
+        const bool allow224 = g_tile224 && (!h->pipelined || g_tile224_pipe == 1 || (g_tile224_pipe == 2 && (a.M >> 8) * (a.N >> 8) > 256));
+        const bool t224 = allow224 && rows > 0 && pick_tile_rows(rows, a.N, ln) == 224;
+        if (t224) a.M = (rows + 223) / 224 * 224;                 // the workspace holds 256 rows beyond the 256-padded rows
+        if (W.scale) { a.wscale = W.scale; return launch_gemm_mt(a, epi, t224 ? 224 : 256, s); }
+        return t224 ? launch_gemm_mt(a, epi, 224, s) : launch_gemm256(a, epi, s);
+    }
+    if (ln) return hipErrorInvalidValue;
+    if (W.scale) {
+        const hipError_t e = launch_dequant_fp8((const unsigned char*)W.p, W.scale, h->wstage, pad_to(a.N, 16), a.K, s);
+        if (e != hipSuccess) return e;
+        a.W = h->wstage;
+    }
+    if ((a.M & 63) == 0 && (a.N & 63) == 0 && ((a.M & 127) || (a.N & 127) || (a.M >> 7) * (a.N >> 7) < g_tiny_tiles))
+        return launch_gemm64(a, epi, s);
+    return launch_gemm(a, epi, s);
 }
 
 int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef& W, const float* bias, int M, int N,
          int K, void* out, int ldo, const float* resid = nullptr, int ldr = 0) {
-    hipError_t e;
-    const bf16_t* Wb = stage_weight(h, s, W, N, K, &e);
-    HIP_OK(h, e);
     // algorithmic work: the VALID rows (h->prof_rows), not the 128-padded M that is launched; bytes = operands once +
     // the output (+ the fp32 residual read)
     const double R = h->prof_rows, osz = (epi == EPI_BIAS_RESID_F32 || epi == EPI_BIAS_F32 || epi == EPI_PATCH_F32) ? 4.0 : 2.0;
     ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * R * N * K, 2.0 * R * K + 2.0 * N * K + R * N * (osz + (resid ? 4.0 : 0.0)));
     GemmArgs a{};
-    a.A = A; a.lda = lda; a.W = Wb; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
+    a.A = A; a.lda = lda; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
     a.resid = resid; a.ldr = ldr;
-    HIP_OK(h, launch_gemm_auto(a, epi, s, (int)h->prof_rows, h->pipelined));
+    HIP_OK(h, launch_gemm_auto(h, a, W, epi, s, (int)h->prof_rows));
     return 0;
 }
 
@@ -289,7 +286,6 @@ std::atomic<bool> g_fuse_ln{!env_flag("GITCAP_NO_GEMM_LN")};
 int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const WRef& W, const float* bias, int M, int N,
             int K, float* xout, const float* resid, const float* ln_g, const float* ln_b, float eps, int rows,
             bf16_t* ln_out, float* scratch, const float* addv = nullptr, int add_div = 1, int add_mod = 1, float* ln_f32 = nullptr) {
-    hipError_t e;
     GemmArgs a{};
     a.A = A; a.lda = lda; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = xout; a.ldo = N; a.resid = resid; a.ldr = N;
     a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = eps; a.ln_out = ln_out; a.ld_ln = N; a.ln_stats = h->ln_stats; a.ln_cnt = h->ln_cnt;
@@ -299,11 +295,9 @@ int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const
     // them has finished its K loop (that is what the exchange waits for) -- as long as both views have the same row stride
     const bool alias_ok = (const void*)A != (const void*)ln_out || lda == N;
     if (g_fuse_ln && alias_ok && gemm256_ln_ok(a) && (M >> 8) * (N >> 8) >= g_small_tiles && (post ? (xout && !addv && !ln_f32) : resid != nullptr)) {
-        a.W = stage_weight(h, s, W, N, K, &e);
-        HIP_OK(h, e);
         const double R = h->prof_rows;      // A + W + fp32 out + bf16 LayerNorm out (+ fp32 residual read)
         ProfScope ps(h, GITCAP_PROF_GEMM_LN, s, 2.0 * R * N * K, 2.0 * R * K + 2.0 * N * K + R * N * ((xout ? 4.0 : 0.0) + 2.0 + (ln_f32 ? 4.0 : 0.0) + (resid ? 4.0 : 0.0)));
-        HIP_OK(h, launch_gemm_auto(a, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s, rows, h->pipelined));
+        HIP_OK(h, launch_gemm_auto(h, a, W, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s, rows));
         return 0;
     }
     int rc;
@@ -759,14 +753,11 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
         HIP_OK(h, launch_im2col(src.f32, h->patches, nf, c.image_size, c.patch_size, h->Kp, s));
     }
     {
-        hipError_t e;
-        const bf16_t* Wb = stage_weight(h, s, h->patch_w, Dv, h->Kp, &e);
-        HIP_OK(h, e);
         ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * P * Dv * (3.0 * c.patch_size * c.patch_size), 2.0 * P * h->Kp + 2.0 * Dv * h->Kp + 4.0 * P * Dv);
         GemmArgs a{};
-        a.A = h->patches; a.lda = h->Kp; a.W = Wb; a.bias = nullptr; a.M = Pp; a.N = Dv; a.K = h->Kp;
+        a.A = h->patches; a.lda = h->Kp; a.bias = nullptr; a.M = Pp; a.N = Dv; a.K = h->Kp;
         a.out = h->x; a.ldo = Dv; a.pos = h->pos; a.tokens_per_frame = N; a.patches_per_frame = h->G * h->G; a.valid_rows = P;
-        HIP_OK(h, launch_gemm_auto(a, EPI_PATCH_F32, s, P, h->pipelined));
+        HIP_OK(h, launch_gemm_auto(h, a, h->patch_w, EPI_PATCH_F32, s, P));
     }
     HIP_OK(h, launch_cls_rows(h->x, h->cls, h->pos, nf, N, Dv, s));
     h->prof_rows = rows;
@@ -1032,6 +1023,18 @@ int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float
     if (tile != 64 && tile != 128 && tile != 256 && tile != 224 && tile != 257) return GITCAP_ERR_ARG;
     hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, (hipStream_t)stream);
     return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
+}
+
+// The e4m3-weight form of the big-tile kernel (gemm_mt.hip) alone: W8 = OCP e4m3 bytes [N][K], wscale = one power-of-two scale
+// per weight row; tile_rows = 224 or 256 (M % tile_rows == 0; with 224 A must be readable 16 rows past M).
+int gitcap_dbg_gemm_wq(const void* A, const void* W8, const float* wscale, const float* bias, const float* resid, void* out,
+                        int M, int N, int K, int epi, int tile_rows, void* stream) {
+    GemmArgs a{};
+    a.A = (const bf16_t*)A; a.lda = K; a.W = (const bf16_t*)W8; a.wscale = wscale; a.bias = bias; a.M = M; a.N = N; a.K = K;
+    a.out = out; a.ldo = N; a.resid = resid; a.ldr = N;
+    if (epi < 0 || epi > EPI_BIAS_F32 || !wscale) return GITCAP_ERR_ARG;
+    if (!gemm_mt_ok(a, tile_rows)) return GITCAP_ERR_ARG;
+    return launch_gemm_mt(a, epi, tile_rows, (hipStream_t)stream) == hipSuccess ? 0 : GITCAP_ERR_HIP;
 }
 
 // GEMM + bias [+ resid] + LayerNorm: fused = 1 the EPI_RESID_LN_* epilogue of the 256x256 kernel, 0 = GEMM (tile) then the

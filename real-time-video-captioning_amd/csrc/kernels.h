@@ -18,7 +18,8 @@ enum GemmEpi {
 };
 struct GemmArgs {
     const bf16_t* A; int lda;     // activations [M][lda], M multiple of 128 (padded rows are junk)
-    const bf16_t* W;              // weights [N][K] (torch Linear layout), N multiple of 128
+    const bf16_t* W;              // weights [N][K] (torch Linear layout), N multiple of 128; gemm_mt.hip only: OCP e4m3 bytes when wscale != nullptr
+    const float* wscale;          // nullable: [N] per-row power-of-two scale of e4m3 weights (launch_gemm_mt)
     const float* bias;            // [N] or nullptr
     int M, N, K;                  // K multiple of 64
     void* out; int ldo;
