@@ -212,11 +212,6 @@ int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launche
  * kernel (M % 224 == 0, A readable 16 rows past M), 257 = that kernel on 256 rows. */
 int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float* resid, void* out,
                     int M, int N, int K, int epi, int tile, void* stream);
-/* The same product with e4m3 weight storage read directly by the big-tile kernel (csrc/gemm_mt.hip): W8 = OCP e4m3 bytes [N][K],
- * wscale [N] = one power-of-two scale per weight row; tile_rows = 224 or 256, M % tile_rows == 0 (224: A readable 16 rows past M).
- * Bitwise equal to gitcap_dbg_gemm on the bf16 weights W8 * wscale. */
-int gitcap_dbg_gemm_wq(const void* A, const void* W8, const float* wscale, const float* bias, const float* resid, void* out,
-                        int M, int N, int K, int epi, int tile_rows, void* stream);
 /* GEMM + bias [+ resid] followed by LayerNorm of the output rows (N = 768 or 1024).  post = 0: out_f32 = x = A W^T + bias +
  * resid, out_bf16 = LN(x) (pre-LN block); post = 1: out_f32 = out_bf16 = LN(x), resid may be NULL (post-LN block).
  * fused = 1: inside the 256x256 kernel (the tiles of a 256-row block exchange segment statistics); fused = 224 / 257: inside the

@@ -34,13 +34,6 @@
 //   RAW  every wave moves pieces of every region, so a region is readable one barrier after BOTH groups' covering wait:
 //        W(t+1): vmcnt(6) in L2(t) (8t+4 / 8t+5) -> first read C3(t) (8t+7 / 8t+8).  A(t+1): vmcnt(4) in L3(t)
 //        (8t+6 / 8t+7) -> first read L0(t+1) (8t+8 / 8t+9).
-//
-// W8 = true: the weight operand is stored as OCP e4m3 bytes [N][K] + one power-of-two scale per row (gitcap_set_weight_storage).
-// A W region is then 128 rows x 64 B (one 1-KiB LDS-DMA piece of 16 rows per wave; 16-B units XOR-swizzled by (row>>2)&3,
-// conflict-free ds_read_b64), a fragment is 8 bytes expanded in registers to the bf16 MFMA operand
-// (v_cvt_scalef32_pk_bf16_fp8, exact) and the row scale multiplies the fp32 accumulator in the epilogue: scaling by 2^k
-// commutes with every rounding of the accumulation, so the result is bit for bit that of bf16 storage of the same
-// values -- without the staging launch and with half the weight bytes through the LDS-DMA path.
 #include "gemm_epilogue.h"
 #include "host_logic.h"
 
@@ -61,7 +54,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_mt;
 
 // ---- plain epilogues: the wave's 64(n) x 16*NM(m) sub-block through its LDS region to full row segments -----------
 // acc[i][j]: n = nw + i*16 + 4*(lane>>4) + r, m = mw + j*16 + (lane&15)
-template <int EPI, int NM, bool W8>
+template <int EPI, int NM>
 __device__ __forceinline__ void epilogue_block(const GemmArgs& a, const f32x4 (&acc)[4][8], const int j0, char* ep,
                                                const int mw, const int nw, const int lane) {
     const int frow = lane & 15, fq = lane >> 4;
@@ -76,12 +69,10 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& a, const f32x4 (&
         const int nl = i * 16 + fq * 4;
         f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (EPI != EPI_PATCH_F32 && a.bias) bias4 = *(const f32x4*)(a.bias + nw + nl);
-        f32x4 sc4 = f32x4{1.f, 1.f, 1.f, 1.f};
-        if (W8) sc4 = *(const f32x4*)(a.wscale + nw + nl);
 #pragma unroll
         for (int j = 0; j < NM; ++j) {
             const int ml = j * 16 + frow;
-            f32x4 v = W8 ? acc[i][j0 + j] * sc4 + bias4 : acc[i][j0 + j] + bias4;
+            f32x4 v = acc[i][j0 + j] + bias4;
             if (EPI == EPI_BIAS_QGELU_BF16) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
@@ -135,7 +126,7 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& a, const f32x4 (&
 // row to global memory (16-byte write-through stores), one arrival per tile on the row block's self-resetting barrier, then
 // every wave fetches the 128 B of statistics of each of its rows (sc1 loads), merges the N/64 segments in the canonical
 // order and normalises its registers.
-template <bool POST, int MT, bool W8>
+template <bool POST, int MT>
 __device__ __forceinline__ void epilogue_tile_ln(const GemmArgs& a, const f32x4 (&acc)[4][8], char* smem, const int m0,
                                                  const int n0, const int tm, const int tn, const int wid, const int wm,
                                                  const int wn, const int lane) {
@@ -151,12 +142,9 @@ __device__ __forceinline__ void epilogue_tile_ln(const GemmArgs& a, const f32x4 
     unsigned my_gen = 0;
     if (threadIdx.x == 0) my_gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     f32x4 xr[4 * MT];
-    f32x4 bias4[4], sc4[4];
+    f32x4 bias4[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        bias4[i] = a.bias ? *(const f32x4*)(a.bias + nw + i * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        sc4[i] = W8 ? *(const f32x4*)(a.wscale + nw + i * 16 + fq * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
-    }
+    for (int i = 0; i < 4; ++i) bias4[i] = a.bias ? *(const f32x4*)(a.bias + nw + i * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 2; ++c) {                          // m-tiles 0-3, then 4 .. MT-1
         constexpr int NM0 = 4;
@@ -165,7 +153,7 @@ __device__ __forceinline__ void epilogue_tile_ln(const GemmArgs& a, const f32x4 
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (j < nm) *(f32x4*)(ep + (j * 16 + frow) * RS + (i * 16 + fq * 4) * 4) = W8 ? acc[i][j0 + j] * sc4[i] + bias4[i] : acc[i][j0 + j] + bias4[i];
+                if (j < nm) *(f32x4*)(ep + (j * 16 + frow) * RS + (i * 16 + fq * 4) * 4) = acc[i][j0 + j] + bias4[i];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
@@ -259,7 +247,7 @@ __device__ __forceinline__ void epilogue_tile_ln(const GemmArgs& a, const f32x4 
     }
 }
 
-template <int EPI, int MT, bool W8>
+template <int EPI, int MT>
 __global__ __launch_bounds__(512, 2) void gemm_mt_kernel(GemmArgs a) {
     static_assert(MT == 7 || MT == 8, "m-tiles per wave");
     constexpr bool LN = (EPI == EPI_RESID_LN_PRE || EPI == EPI_RESID_LN_POST);
@@ -280,11 +268,9 @@ __global__ __launch_bounds__(512, 2) void gemm_mt_kernel(GemmArgs a) {
     }
     const int m0 = tm * BM, n0 = tn << 8;
 
-    // ---- LDS-DMA source addresses: wave w moves pieces 2w, 2w+1 (8 rows each) of every 128-row bf16 region; of an e4m3
-    //      W region (128 rows x 64 B) the one piece w (16 rows)
+    // ---- LDS-DMA source addresses: wave w moves pieces 2w, 2w+1 (8 rows each) of every 128-row region
     const bf16_t* srcW[2];
     const bf16_t* srcA[2];
-    const unsigned char* srcW8 = nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (wid * 2 + i) * 8 + (lane >> 3);
@@ -292,24 +278,15 @@ __global__ __launch_bounds__(512, 2) void gemm_mt_kernel(GemmArgs a) {
         srcW[i] = a.W + (size_t)(n0 + row) * a.K + chunk * 8;
         srcA[i] = a.A + (size_t)(m0 + row) * a.lda + chunk * 8;
     }
-    if (W8) {
-        const int row = wid * 16 + (lane >> 2);
-        srcW8 = (const unsigned char*)a.W + (size_t)(n0 + row) * a.K + (((lane & 3) ^ ((row >> 2) & 3)) << 4);
-    }
     const size_t hiW = (size_t)128 * a.K, hiA = (size_t)WR * a.lda;
     const int dma_off = wid * 2048;
 
     // ---- fragment read offsets (bytes inside a stage)
     const int frow = lane & 15, fq = lane >> 4;
     const int g = (frow >> 1) & 7;
-    const int offW = W8 ? (wn >> 1) * HALF + ((wn & 1) * 64 + frow) * 64       // + i*1024; 8 bytes per lane and k-step
-                        : (wn >> 1) * HALF + ((wn & 1) * 64 + frow) * 128;     // + i*2048
+    const int offW = (wn >> 1) * HALF + ((wn & 1) * 64 + frow) * 128;      // + i*2048
     const int offA = (2 + wm) * HALF + frow * 128;                         // + j*2048
-    const int c0 = ((0 + fq) ^ g) << 4, c1 = ((4 + fq) ^ g) << 4;          // k-step 0 / 1 chunk offsets (bf16 regions)
-    // e4m3 region: 8-byte chunk ks*4 + fq = half (fq & 1) of the 16-byte unit ks*2 + (fq >> 1), units swizzled by (row>>2)&3
-    const int w8s = (frow >> 2) & 3;
-    const int w8c0 = (((0 + (fq >> 1)) ^ w8s) << 4) + (fq & 1) * 8, w8c1 = (((2 + (fq >> 1)) ^ w8s) << 4) + (fq & 1) * 8;
-    constexpr int WSTEP = W8 ? 1024 : 2048;                                // bytes between a wave's 16-row W tiles
+    const int c0 = ((0 + fq) ^ g) << 4, c1 = ((4 + fq) ^ g) << 4;          // k-step 0 / 1 chunk offsets
 
     f32x4 acc[4][8];
 #pragma unroll
@@ -319,23 +296,12 @@ __global__ __launch_bounds__(512, 2) void gemm_mt_kernel(GemmArgs a) {
 
     // which = 0 W-lo, 1 W-hi, 2 A-g0, 3 A-g1
     auto dma_region = [&](char* stage, int which, int k0) {
-        if (W8 && which < 2) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(srcW8 + (which & 1) * hiW + k0), LDS_PTR(stage + which * HALF + wid * 1024), 16, 0, 0);
-            return;
-        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bf16_t* src = (which < 2 ? srcW[i] + (which & 1) * hiW : srcA[i] + (which & 1) * hiA) + k0;
             __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(stage + which * HALF + dma_off + i * 1024), 16, 0, 0);
         }
     };
-    // one W fragment (16 weight rows x 32 k): bf16 -> 16 bytes as stored; e4m3 -> 8 bytes, expanded exactly (scale 1;
-    // the row's power-of-two scale is applied to the accumulator in the epilogue)
-    auto read_w = [&](const char* p, int cbf, int c8) -> bf16x8 {
-        if (W8) return fp8x8_to_bf16x8(*(const uint2*)(p + c8), 1.0f);
-        return *(const bf16x8*)(p + cbf);
-    };
-    // (an e4m3 W region is ONE LDS-DMA instruction per wave, a bf16 region two: the counted waits below differ accordingly)
 
     const int nt = a.K >> 6;
     // prologue: tile 0 (W, A) and W of tile 1; the counted wait leaves W(1) in flight
@@ -346,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mt_kernel(GemmArgs a) {
     if (nt > 1) {
         dma_region(smem + STAGE, 0, 64);
         dma_region(smem + STAGE, 1, 64);
-        if (W8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         WAIT_VM0();
     }
@@ -355,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mt_kernel(GemmArgs a) {
 
     bf16x8 wf0[4], wf1[4], aX[4], aY[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wf0[i] = read_w(smem + offW + i * WSTEP, c0, w8c0);
+    for (int i = 0; i < 4; ++i) wf0[i] = *(const bf16x8*)(smem + offW + i * 2048 + c0);
 
     for (int t = 0; t < nt; ++t) {
         const char* sb = smem + (t & 1) * STAGE;
@@ -376,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mt_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) aY[j] = *(const bf16x8*)(sb + offA + (4 + j) * 2048 + c0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wf1[i] = read_w(sb + offW + i * WSTEP, c1, w8c1);
+        for (int i = 0; i < 4; ++i) wf1[i] = *(const bf16x8*)(sb + offW + i * 2048 + c1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -413,9 +379,9 @@ __global__ __launch_bounds__(512, 2) void gemm_mt_kernel(GemmArgs a) {
         SCHED_FENCE();
         BARRIER();
         // ---------------- L2: DMA W-lo of tile t+2; retire W of tile t+1 -----------------------------------------
-        if (has2) {                                 // leaves A-g0, A-g1 of tile t+1 and W-lo of tile t+2 in flight
+        if (has2) {
             dma_region(cb, 0, k2);
-            if (W8) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else if (has1) {
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         }
@@ -440,9 +406,9 @@ __global__ __launch_bounds__(512, 2) void gemm_mt_kernel(GemmArgs a) {
         SCHED_FENCE();
         BARRIER();
         // ---------------- L3: DMA W-hi of tile t+2; retire A of tile t+1 -----------------------------------------
-        if (has2) {                                 // leaves W-lo, W-hi of tile t+2 in flight
+        if (has2) {
             dma_region(cb, 1, k2);
-            if (W8) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             WAIT_VM0();
         }
@@ -453,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mt_kernel(GemmArgs a) {
         __builtin_amdgcn_s_setprio(1);
         // (on the last tile this reads the other stage's stale image: in bounds, never used)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wf0[i] = read_w(nb + offW + i * WSTEP, c0, w8c0);
+        for (int i = 0; i < 4; ++i) wf0[i] = *(const bf16x8*)(nb + offW + i * 2048 + c0);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -473,15 +439,15 @@ __global__ __launch_bounds__(512, 2) void gemm_mt_kernel(GemmArgs a) {
 
     // ---- epilogue through LDS (the operand stages are dead after the last barrier) ----
     if (LN) {
-        epilogue_tile_ln<EPI == EPI_RESID_LN_POST, MT, W8>(a, acc, smem, m0, n0, tm, tn, wid, wm, wn, lane);
+        epilogue_tile_ln<EPI == EPI_RESID_LN_POST, MT>(a, acc, smem, m0, n0, tm, tn, wid, wm, wn, lane);
     } else {
         char* ep = smem + wid * EPI_REGION;
-        epilogue_block<EPI, 4, W8>(a, acc, 0, ep, m0 + wm * WR, n0 + wn * 64, lane);
-        epilogue_block<EPI, NB, W8>(a, acc, 4, ep, m0 + wm * WR, n0 + wn * 64, lane);
+        epilogue_block<EPI, 4>(a, acc, 0, ep, m0 + wm * WR, n0 + wn * 64, lane);
+        epilogue_block<EPI, NB>(a, acc, 4, ep, m0 + wm * WR, n0 + wn * 64, lane);
     }
 }
 
-template <int EPI, int MT, bool W8>
+template <int EPI, int MT>
 hipError_t launch_t(const GemmArgs& a0, hipStream_t s) {
     static bool attr_done[64] = {false};            // per device: the attribute belongs to the device's code object
     int dev_ = 0;
@@ -490,7 +456,7 @@ hipError_t launch_t(const GemmArgs& a0, hipStream_t s) {
     constexpr bool LN = (EPI == EPI_RESID_LN_PRE || EPI == EPI_RESID_LN_POST);
     constexpr int LDS = LN ? LDS_LN : LDS_PLAIN;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_mt_kernel<EPI, MT, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_mt_kernel<EPI, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -501,21 +467,21 @@ hipError_t launch_t(const GemmArgs& a0, hipStream_t s) {
         a.ln_rowblock_map = ln_use_rowblock_map(nrb, ntn) ? 1 : 0;
         if (a.ln_rowblock_map) grid = ln_grid_size(nrb, ntn);
     }
-    hipLaunchKernelGGL((gemm_mt_kernel<EPI, MT, W8>), dim3(grid), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((gemm_mt_kernel<EPI, MT>), dim3(grid), dim3(512), LDS, s, a);
     return hipGetLastError();
 }
 
-template <int MT, bool W8>
+template <int MT>
 hipError_t launch_mt(const GemmArgs& a, int epi, hipStream_t s) {
     switch (epi) {
-        case EPI_BIAS_BF16: return launch_t<EPI_BIAS_BF16, MT, W8>(a, s);
-        case EPI_BIAS_QGELU_BF16: return launch_t<EPI_BIAS_QGELU_BF16, MT, W8>(a, s);
-        case EPI_BIAS_GELU_BF16: return launch_t<EPI_BIAS_GELU_BF16, MT, W8>(a, s);
-        case EPI_BIAS_RESID_F32: return launch_t<EPI_BIAS_RESID_F32, MT, W8>(a, s);
-        case EPI_BIAS_F32: return launch_t<EPI_BIAS_F32, MT, W8>(a, s);
-        case EPI_PATCH_F32: return launch_t<EPI_PATCH_F32, MT, W8>(a, s);
-        case EPI_RESID_LN_PRE: return gemm_mt_ln_ok(a, 32 * MT) && a.resid ? launch_t<EPI_RESID_LN_PRE, MT, W8>(a, s) : hipErrorInvalidValue;
-        case EPI_RESID_LN_POST: return gemm_mt_ln_ok(a, 32 * MT) && a.out ? launch_t<EPI_RESID_LN_POST, MT, W8>(a, s) : hipErrorInvalidValue;
+        case EPI_BIAS_BF16: return launch_t<EPI_BIAS_BF16, MT>(a, s);
+        case EPI_BIAS_QGELU_BF16: return launch_t<EPI_BIAS_QGELU_BF16, MT>(a, s);
+        case EPI_BIAS_GELU_BF16: return launch_t<EPI_BIAS_GELU_BF16, MT>(a, s);
+        case EPI_BIAS_RESID_F32: return launch_t<EPI_BIAS_RESID_F32, MT>(a, s);
+        case EPI_BIAS_F32: return launch_t<EPI_BIAS_F32, MT>(a, s);
+        case EPI_PATCH_F32: return launch_t<EPI_PATCH_F32, MT>(a, s);
+        case EPI_RESID_LN_PRE: return gemm_mt_ln_ok(a, 32 * MT) && a.resid ? launch_t<EPI_RESID_LN_PRE, MT>(a, s) : hipErrorInvalidValue;
+        case EPI_RESID_LN_POST: return gemm_mt_ln_ok(a, 32 * MT) && a.out ? launch_t<EPI_RESID_LN_POST, MT>(a, s) : hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;
 }
@@ -534,6 +500,5 @@ bool gemm_mt_ln_ok(const GemmArgs& a, int tile_rows) {
 // tile_rows = 224: the A buffer must be readable up to row M + 15 (the DMA pieces of the second m group stay whole)
 hipError_t launch_gemm_mt(const GemmArgs& a, int epi, int tile_rows, hipStream_t s) {
     if (!gemm_mt_ok(a, tile_rows)) return hipErrorInvalidValue;
-    if (a.wscale) return tile_rows == 224 ? launch_mt<7, true>(a, epi, s) : launch_mt<8, true>(a, epi, s);     // W = e4m3 bytes + row scales
-    return tile_rows == 224 ? launch_mt<7, false>(a, epi, s) : launch_mt<8, false>(a, epi, s);
+    return tile_rows == 224 ? launch_mt<7>(a, epi, s) : launch_mt<8>(a, epi, s);
 }

@@ -54,7 +54,12 @@ struct gitcap {
     std::map<std::string, DevTensor> w;
     std::map<std::string, float*> wscale;          // e4m3 storage: per-row scales of the GEMM weights
     bool finalized = false, fp8 = false;
-    bf16_t* wstage = nullptr;                       // e4m3 storage: bf16 staging panel of the big-tile GEMMs
+    bf16_t* wstage = nullptr;                       // e4m3 storage: bf16 staging panel of a single GEMM
+    bf16_t* lstage = nullptr;                       // e4m3 storage: bf16 staging of the (up to 4) matrices of one layer
+    size_t lstage_elems = 0;
+    const void* staged_src[4] = {nullptr, nullptr, nullptr, nullptr};   // which e4m3 matrices lstage currently holds, and where
+    const bf16_t* staged_dst[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n_staged = 0;
     // opt-in export of the decoder's per-layer hidden states (gitcap_hidden_states_enable): [L+1][rows][D] fp32
     bool want_hidden = false;
     float *hid_img = nullptr, *hid_txt = nullptr;
@@ -237,29 +242,60 @@ int ln(gitcap* h, hipStream_t s, const float* x, int ldx, const float* g, const 
 // take 256(n) x 224(m) tiles where that turns partial rounds on the 256 CUs into full ones (the bench shape: every GEMM,
 // -12.5 % K-loop time).  All tile kernels produce bitwise identical results (tests/test_kernels_gpu.py), so the choice
 // only affects speed.
-// Weights: bf16, or e4m3 bytes + row scales (W.scale != nullptr).  The big-tile kernel of gemm_mt.hip reads e4m3 panels
-// directly (LDS-DMA of the bytes, expansion on the fragment read, row scale on the accumulator: no staging launch); the
-// small-tile kernels read them through the bf16 staging buffer, expanded right before the launch on the same stream (the
-// panel is a few MB and stays in L2 / the Infinity Cache; HBM sees the e4m3 bytes).
+// Weights: bf16, or e4m3 bytes + row scales (W.scale != nullptr).  The tile kernels read e4m3 panels through bf16
+// staging (a few MB: it stays in L2 / the Infinity Cache; HBM sees the e4m3 bytes): the four matrices of a transformer
+// layer are expanded by ONE launch at the head of the layer (stage_layer), anything else right before its GEMM.
+// Two alternatives were built in round 3 and measured slower at the configs[4] shape (bit-exact both): reading the bytes
+// directly in the GEMM (LDS-DMA of the e4m3 panel, expansion on the fragment read, row scale on the accumulator): 10-25 %
+// slower per launch, 32 v_cvt_scalef32_pk_bf16_fp8 per wave and K-tile next to 56-64 MFMAs
+// (profiles/r03_gemm_e4m3_direct_vs_bf16.txt); expanding panel i+1 on a side stream while GEMM i runs (two-slot ring,
+// events both ways): image pass 11.0 vs 10.3 ms, a cross-stream event hand-off costs more than the 3 us it hides.
 hipError_t launch_gemm_auto(gitcap* h, GemmArgs a, const WRef& W, int epi, hipStream_t s, int rows) {
     const bool ln = epi == EPI_RESID_LN_PRE || epi == EPI_RESID_LN_POST;
-    a.W = (const bf16_t*)W.p; a.wscale = nullptr;
+    a.W = (const bf16_t*)W.p;
+    if (W.scale) {
+        const bf16_t* st = nullptr;
+        for (int i = 0; i < h->n_staged; ++i)
+            if (h->staged_src[i] == W.p) st = h->staged_dst[i];                // expanded at the head of the layer
+        if (!st) {
+            const hipError_t e = launch_dequant_fp8((const unsigned char*)W.p, W.scale, h->wstage, pad_to(a.N, 16), a.K, s);
+            if (e != hipSuccess) return e;
+            st = h->wstage;
+        }
+        a.W = st;
+    }
     if (gemm256_ok(a) && (a.M >> 8) * (a.N >> 8) >= g_small_tiles) {
         const bool allow224 = g_tile224 && (!h->pipelined || g_tile224_pipe == 1 || (g_tile224_pipe == 2 && (a.M >> 8) * (a.N >> 8) > 256));
         const bool t224 = allow224 && rows > 0 && pick_tile_rows(rows, a.N, ln) == 224;
         if (t224) a.M = (rows + 223) / 224 * 224;                 // the workspace holds 256 rows beyond the 256-padded rows
-        if (W.scale) { a.wscale = W.scale; return launch_gemm_mt(a, epi, t224 ? 224 : 256, s); }
         return t224 ? launch_gemm_mt(a, epi, 224, s) : launch_gemm256(a, epi, s);
     }
     if (ln) return hipErrorInvalidValue;
-    if (W.scale) {
-        const hipError_t e = launch_dequant_fp8((const unsigned char*)W.p, W.scale, h->wstage, pad_to(a.N, 16), a.K, s);
-        if (e != hipSuccess) return e;
-        a.W = h->wstage;
-    }
     if ((a.M & 63) == 0 && (a.N & 63) == 0 && ((a.M & 127) || (a.N & 127) || (a.M >> 7) * (a.N >> 7) < g_tiny_tiles))
         return launch_gemm64(a, epi, s);
     return launch_gemm(a, epi, s);
+}
+
+// e4m3 storage: expand the matrices of one transformer layer ([rows][K] each) into the layer staging area with ONE
+// launch; the GEMMs of the layer then find them through staged_src.  Stream ordered: the previous layer's GEMMs (which read
+// the area) are in front of this launch on the same stream.  No-op for bf16 storage.
+int stage_layer(gitcap* h, hipStream_t s, const WRef* const* Ws, const int* rows, const int* Ks, int n) {
+    h->n_staged = 0;
+    if (n <= 0 || n > 4 || !Ws[0]->scale || !h->lstage) return 0;
+    DequantBatch b{};
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t elems = (size_t)pad_to(rows[i], 16) * Ks[i];
+        if (off + elems > h->lstage_elems) return fail(h, GITCAP_ERR_STATE, "stage_layer: staging area too small");
+        b.w8[i] = (const unsigned char*)Ws[i]->p; b.scale[i] = Ws[i]->scale; b.out[i] = h->lstage + off; b.K[i] = Ks[i];
+        b.n16[i] = (int64_t)(elems / 16);
+        h->staged_src[i] = Ws[i]->p; h->staged_dst[i] = h->lstage + off;
+        off += elems;
+    }
+    b.n = n;
+    HIP_OK(h, launch_dequant_fp8_batch(b, s));
+    h->n_staged = n;
+    return 0;
 }
 
 int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef& W, const float* bias, int M, int N,
@@ -335,6 +371,7 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
     const int D = h->D, Dv = h->Dv, rows = B * S, Mp = pad_to(rows, 256);
     int rc;
     h->prof_rows = rows;
+    h->n_staged = 0;
     // 'linearLn' projection: Linear(Dv -> D) + LayerNorm
     if ((rc = gemm_ln(h, s, true, h->hb, Dv, h->vproj_w, h->vproj_b, Mp, D, Dv, h->x, nullptr, h->vproj_lnw, h->vproj_lnb,
                       c.proj_ln_eps, rows, h->hb, h->tmp))) return rc;
@@ -348,6 +385,11 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
         const DecLayer& L = h->dec[l];
         bf16_t* kv = h->kv_img + (size_t)l * kv_layer;
         if (l + 1 < c.dec_layers || hid) {
+            {   // e4m3 storage: the layer's four matrices -> bf16 staging, one launch
+                const WRef* ws[4] = {&L.qkvw, &L.aow, &L.fc1w, &L.fc2w};
+                const int wr[4] = {3 * D, D, c.dec_ffn, D}, wk[4] = {D, D, D, c.dec_ffn};
+                if ((rc = stage_layer(h, s, ws, wr, wk, 4))) return rc;
+            }
             if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, D, L.qkvw, L.qkvb, Mp, 3 * D, D, kv, 3 * D))) return rc;
             {
                 ProfScope ps(h, GITCAP_PROF_ATTN_FULL, s, 4.0 * B * c.dec_heads * (double)S * S * 64, 0.0);
@@ -697,6 +739,12 @@ int gitcap_finalize_weights(gitcap_t* h) {
                 }
             int rc = ws_alloc(h, &h->wstage, mx);
             if (rc) return rc;
+            auto pe = [](int64_t r, int64_t k) { return (size_t)pad_to((int)r, 16) * (size_t)k; };
+            const gitcap_config& c = h->c;
+            const size_t enc_l = pe(3 * c.enc_width, c.enc_width) + pe(c.enc_width, c.enc_width) + 2 * pe(c.enc_ffn, c.enc_width);
+            const size_t dec_l = pe(3 * c.dec_width, c.dec_width) + pe(c.dec_width, c.dec_width) + 2 * pe(c.dec_ffn, c.dec_width);
+            h->lstage_elems = std::max(enc_l, dec_l);
+            if ((rc = ws_alloc(h, &h->lstage, h->lstage_elems))) return rc;
         }
     }
     h->patch_w = Wt("enc.patch_w"); h->cls = F("enc.cls"); h->pos = F("enc.pos");
@@ -759,18 +807,23 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
         a.out = h->x; a.ldo = Dv; a.pos = h->pos; a.tokens_per_frame = N; a.patches_per_frame = h->G * h->G; a.valid_rows = P;
         HIP_OK(h, launch_gemm_auto(h, a, h->patch_w, EPI_PATCH_F32, s, P));
     }
-    HIP_OK(h, launch_cls_rows(h->x, h->cls, h->pos, nf, N, Dv, s));
     h->prof_rows = rows;
-    // ln_pre (fp32, in place: the residual stream) and the first block's LN1 (bf16: the first q|k|v operand) in one pass
+    // ln_pre (fp32, in place: the residual stream) and the first block's LN1 (bf16: the first q|k|v operand) in one pass;
+    // the same pass supplies the CLS rows (cls + pos[0], row frame * N) that the patch GEMM does not write
     {
         const bool canon = Dv == 64 || Dv == 128 || Dv == 256 || Dv == 512 || Dv == 768 || Dv == 1024;
         if (canon) {
             ProfScope ps(h, GITCAP_PROF_ROWOPS, s, 0.0, (double)rows * Dv * 10.0);
             LnArgs a{h->x, Dv, h->ln_pre_w, h->ln_pre_b, c.enc_ln_eps, rows, Dv, h->x, Dv, h->hb, Dv, nullptr, 1, 1,
-                     h->enc[0].ln1w, h->enc[0].ln1b, c.enc_ln_eps};
+                     h->enc[0].ln1w, h->enc[0].ln1b, c.enc_ln_eps, h->cls, h->pos, N};
             HIP_OK(h, launch_layernorm(a, s));
         } else {
-            if ((rc = ln(h, s, h->x, Dv, h->ln_pre_w, h->ln_pre_b, c.enc_ln_eps, rows, Dv, h->x, Dv, nullptr, 0))) return rc;
+            {
+                ProfScope ps(h, GITCAP_PROF_ROWOPS, s, 0.0, (double)rows * Dv * 8.0);
+                LnArgs a{h->x, Dv, h->ln_pre_w, h->ln_pre_b, c.enc_ln_eps, rows, Dv, h->x, Dv, nullptr, 0, nullptr, 1, 1,
+                         nullptr, nullptr, 0.f, h->cls, h->pos, N};
+                HIP_OK(h, launch_layernorm(a, s));
+            }
             if ((rc = ln(h, s, h->x, Dv, h->enc[0].ln1w, h->enc[0].ln1b, c.enc_ln_eps, rows, Dv, nullptr, 0, h->hb, Dv))) return rc;
         }
     }
@@ -780,6 +833,11 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
     // LN1 came out of the ln_pre pass above.
     for (int i = 0; i < c.enc_layers; ++i) {
         const EncLayer& L = h->enc[i];
+        {   // e4m3 storage: the layer's four matrices -> bf16 staging, one launch
+            const WRef* ws[4] = {&L.qkvw, &L.projw, &L.fc1w, &L.fc2w};
+            const int wr[4] = {3 * Dv, Dv, c.enc_ffn, Dv}, wk[4] = {Dv, Dv, Dv, c.enc_ffn};
+            if ((rc = stage_layer(h, s, ws, wr, wk, 4))) return rc;
+        }
         if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, Dv, L.qkvw, L.qkvb, Mp, 3 * Dv, Dv, h->qkv, 3 * Dv))) return rc;
         {
             ProfScope ps(h, GITCAP_PROF_ATTN_FULL, s, 4.0 * nf * c.enc_heads * (double)N * N * 64, 0.0);
@@ -1023,18 +1081,6 @@ int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float
     if (tile != 64 && tile != 128 && tile != 256 && tile != 224 && tile != 257) return GITCAP_ERR_ARG;
     hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, (hipStream_t)stream);
     return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
-}
-
-// The e4m3-weight form of the big-tile kernel (gemm_mt.hip) alone: W8 = OCP e4m3 bytes [N][K], wscale = one power-of-two scale
-// per weight row; tile_rows = 224 or 256 (M % tile_rows == 0; with 224 A must be readable 16 rows past M).
-int gitcap_dbg_gemm_wq(const void* A, const void* W8, const float* wscale, const float* bias, const float* resid, void* out,
-                        int M, int N, int K, int epi, int tile_rows, void* stream) {
-    GemmArgs a{};
-    a.A = (const bf16_t*)A; a.lda = K; a.W = (const bf16_t*)W8; a.wscale = wscale; a.bias = bias; a.M = M; a.N = N; a.K = K;
-    a.out = out; a.ldo = N; a.resid = resid; a.ldr = N;
-    if (epi < 0 || epi > EPI_BIAS_F32 || !wscale) return GITCAP_ERR_ARG;
-    if (!gemm_mt_ok(a, tile_rows)) return GITCAP_ERR_ARG;
-    return launch_gemm_mt(a, epi, tile_rows, (hipStream_t)stream) == hipSuccess ? 0 : GITCAP_ERR_HIP;
 }
 
 // GEMM + bias [+ resid] + LayerNorm: fused = 1 the EPI_RESID_LN_* epilogue of the 256x256 kernel, 0 = GEMM (tile) then the

@@ -18,8 +18,7 @@ enum GemmEpi {
 };
 struct GemmArgs {
     const bf16_t* A; int lda;     // activations [M][lda], M multiple of 128 (padded rows are junk)
-    const bf16_t* W;              // weights [N][K] (torch Linear layout), N multiple of 128; gemm_mt.hip only: OCP e4m3 bytes when wscale != nullptr
-    const float* wscale;          // nullable: [N] per-row power-of-two scale of e4m3 weights (launch_gemm_mt)
+    const bf16_t* W;              // weights [N][K] (torch Linear layout), N multiple of 128
     const float* bias;            // [N] or nullptr
     int M, N, K;                  // K multiple of 64
     void* out; int ldo;
@@ -142,13 +141,14 @@ struct LnArgs {
     // optional SECOND LayerNorm of the first one's fp32 output (canonical widths only): out_f32 = LN(x), out_bf16 =
     // LN2(LN(x)) -- ln_pre and the first block's LN1 of the ViT in one pass over the rows.  Same bits as two launches.
     const float* gamma2; const float* beta2; float eps2;
+    // optional: rows with row % cls_period == 0 are not read from x but are cls[c] + cls_pos[c] (the CLS token + its position
+    // embedding of the ViT front end: x[frame * N] of model.py:378's encoder input) -- the row a cls_rows launch would write
+    const float* cls; const float* cls_pos; int cls_period;
 };
 hipError_t launch_layernorm(const LnArgs& a, hipStream_t s);
 
 // frames [nf][3][H][W] f32 -> patches bf16 [nf*G*G][Kp] (k = c*p*p + py*p + px, zero padded)
 hipError_t launch_im2col(const float* frames, bf16_t* patches, int nf, int img, int p, int Kp, hipStream_t s);
-// x[frame*N + 0][:] = cls + pos[0]
-hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int nf, int N, int D, hipStream_t s);
 // out[b][e][s][:] = s < S_img ? img[e][b*S_img + s][:] : txt[e][b*T + s - S_img][:]   (e < n_entries; fp32 rows of D)
 hipError_t launch_gather_hidden(const float* img, const float* txt, float* out, int n_entries, int B, int S_img, int T, int D,
                                 size_t img_entry_stride, size_t txt_entry_stride, hipStream_t s);
@@ -156,6 +156,9 @@ hipError_t launch_gather_hidden(const float* img, const float* txt, float* out, 
 hipError_t launch_cast_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s);
 // e4m3 weight rows [rows][K] (+ per-row power-of-two scale) -> bf16 [rows][K] (exact); K % 16 == 0
 hipError_t launch_dequant_fp8(const unsigned char* w8, const float* scale, bf16_t* out, int rows, int K, hipStream_t s);
+// up to four such matrices in ONE launch (the weights of a transformer layer); n16[i] = rows_i * K_i / 16
+struct DequantBatch { const unsigned char* w8[4]; const float* scale[4]; bf16_t* out[4]; int K[4]; int64_t n16[4]; int n; };
+hipError_t launch_dequant_fp8_batch(const DequantBatch& b, hipStream_t s);
 // text embedding + LN: row m=(r, j) -> token ids[r*ld_ids + j], position t0 + j
 hipError_t launch_embed_text(const int64_t* ids, int ld_ids, int rows, int T, int t0,
                              const float* word, const float* pos, const float* gamma, const float* beta,

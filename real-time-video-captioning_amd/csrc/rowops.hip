@@ -1,6 +1,7 @@
 // HBM-bound row kernels: LayerNorm (one wave per row, 16-byte vector loads), patch gather
 // (im2col of NCHW fp32 frames, coalesced 16-B reads along W), text embedding, argmax.
 #include "kernels.h"
+#include <algorithm>
 #include "ln_canon.h"
 #include "rowln.h"
 
@@ -17,11 +18,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.rows) return;
     const float* xr = a.x + (size_t)row * a.ldx;
+    const bool is_cls = a.cls != nullptr && row % a.cls_period == 0;     // wave-uniform
     f32x4 v[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
-        v[i] = c < a.D ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c >= a.D) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        else if (is_cls) v[i] = *(const f32x4*)(a.cls + c) + *(const f32x4*)(a.cls_pos + c);
+        else v[i] = *(const f32x4*)(xr + c);
     }
     float mean, rstd;
     if (CANON) {
@@ -147,10 +151,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ f
     }
 }
 
-__global__ void cls_rows_kernel(float* x, const float* cls, const float* pos, int nf, int N, int D) {
-    const int f = blockIdx.x;
-    for (int c = threadIdx.x; c < D; c += blockDim.x) x[(size_t)f * N * D + c] = cls[c] + pos[c];
-}
+
 
 __global__ void cast_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n4) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,6 +188,18 @@ __global__ __launch_bounds__(256) void dequant_fp8_kernel(const unsigned char* _
     const unsigned o[8] = {o4l.x, o4l.y, o4l.z, o4l.w, o4h.x, o4h.y, o4h.z, o4h.w};
     *(uint4*)(out + e) = make_uint4(o[0], o[1], o[2], o[3]);
     *(uint4*)(out + e + 8) = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+__global__ __launch_bounds__(256) void dequant_fp8_batch_kernel(DequantBatch b) {
+    const int which = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (which >= b.n || i >= b.n16[which]) return;
+    const int64_t e = i * 16;
+    const float sc = b.scale[which][e / b.K[which]];
+    const uint4 q = *(const uint4*)(b.w8[which] + e);
+    const bf16x8 lo = fp8x8_to_bf16x8(make_uint2(q.x, q.y), sc), hi = fp8x8_to_bf16x8(make_uint2(q.z, q.w), sc);
+    *(uint4*)(b.out[which] + e) = __builtin_bit_cast(uint4, lo);
+    *(uint4*)(b.out[which] + e + 8) = __builtin_bit_cast(uint4, hi);
 }
 
 // ---- text embedding + LayerNorm: one wave per (row, position) (rowln.h) --------------------------
@@ -621,10 +634,7 @@ hipError_t launch_im2col(const float* frames, bf16_t* patches, int nf, int img, 
     return hipGetLastError();
 }
 
-hipError_t launch_cls_rows(float* x, const float* cls, const float* pos, int nf, int N, int D, hipStream_t s) {
-    hipLaunchKernelGGL(cls_rows_kernel, dim3(nf), dim3(256), 0, s, x, cls, pos, nf, N, D);
-    return hipGetLastError();
-}
+
 
 hipError_t launch_cast_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s) {
     if (n % 4) return hipErrorInvalidValue;
@@ -639,6 +649,17 @@ hipError_t launch_gather_hidden(const float* img, const float* txt, float* out, 
     const size_t rows = (size_t)B * n_entries * (S_img + T);
     hipLaunchKernelGGL(gather_hidden_kernel, dim3((unsigned)rows), dim3(256), 0, s, img, txt, out, n_entries, S_img, T, D,
                        img_entry_stride, txt_entry_stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_dequant_fp8_batch(const DequantBatch& b, hipStream_t s) {
+    if (b.n <= 0 || b.n > 4) return hipErrorInvalidValue;
+    int64_t mx = 0;
+    for (int i = 0; i < b.n; ++i) {
+        if ((b.K[i] & 15) || !b.w8[i] || !b.scale[i] || !b.out[i]) return hipErrorInvalidValue;
+        mx = std::max(mx, b.n16[i]);
+    }
+    hipLaunchKernelGGL(dequant_fp8_batch_kernel, dim3((unsigned)((mx + 255) / 256), (unsigned)b.n), dim3(256), 0, s, b);
     return hipGetLastError();
 }
 

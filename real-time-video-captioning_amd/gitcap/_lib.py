@@ -41,7 +41,6 @@ SYMBOLS = {
     "gitcap_profile_read": (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int64),
                                     POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "gitcap_dbg_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "gitcap_dbg_gemm_wq": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gitcap_dbg_gemm_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gitcap_dbg_config": (c_int, [c_int, c_int]),

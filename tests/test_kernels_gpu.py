@@ -216,31 +216,3 @@ def test_gemm_224_row_tiles_layernorm_epilogue(lib, M, N, K, post):
     x = A[:M].float() @ W.float().t() + bias + resid[:M]
     ln = torch.nn.functional.layer_norm(x, (N,), gamma, beta, 1e-5)
     assert torch.allclose(outs[1][0], ln if post else x, rtol=1e-4, atol=2e-4 * K ** 0.5)
-
-
-@pytest.mark.parametrize("N,K", [(768, 768), (3072, 1024), (1024, 4096), (256, 64)])
-def test_gemm_e4m3_weights_read_directly_bitwise_equal_bf16(lib, N, K):
-    """gemm_mt.hip with e4m3 weight storage (LDS-DMA of the bytes, in-register expansion, the row's power-of-two scale on the
-    accumulator) against the 256x256 kernel on the bf16 weights e4m3 x scale: scaling by 2^k commutes with every rounding,
-    so every epilogue must give the same bits, on 224- and on 256-row tiles."""
-    M = 1792
-    g = torch.Generator(device="cuda").manual_seed(N * 7 + K)
-    A = torch.zeros(M + 16, K, device="cuda", dtype=torch.bfloat16)
-    A[:M] = torch.randn(M, K, device="cuda", generator=g).bfloat16()
-    k = torch.randint(-12, 3, (N, 1), device="cuda", generator=g).float()
-    scale = torch.pow(2.0, k)                                                    # per-row power of two
-    W8 = (torch.randn(N, K, device="cuda", generator=g) * 40).clamp(-448, 448).to(torch.float8_e4m3fn)
-    Wb = (W8.float() * scale).bfloat16()
-    assert torch.equal(Wb.float(), W8.float() * scale)                           # exact in bf16
-    W8b = W8.view(torch.uint8).contiguous()
-    bias = torch.linspace(-1, 1, N, device="cuda")
-    resid = torch.randn(M, N, device="cuda", generator=g)
-    sc = scale.flatten().contiguous()
-    for epi, dt in ((0, torch.bfloat16), (1, torch.bfloat16), (2, torch.bfloat16), (3, torch.float32), (4, torch.float32)):
-        ref = torch.empty(M, N, device="cuda", dtype=dt)
-        assert lib.gitcap_dbg_gemm(_p(A), _p(Wb), _p(bias), _p(resid), _p(ref), M, N, K, epi, 256, _stream()) == 0
-        for rows in (224, 256):
-            out = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
-            assert lib.gitcap_dbg_gemm_wq(_p(A), _p(W8b), _p(sc), _p(bias), _p(resid), _p(out), M, N, K, epi, rows, _stream()) == 0
-            torch.cuda.synchronize()
-            assert torch.equal(out, ref), (epi, rows, N, K)
