@@ -56,29 +56,6 @@ __device__ unsigned long long* g_txt_stamps;
 #define TXT_STAMP(i) do {} while (0)
 #endif
 
-// sum over the 16 waves of the block (fixed order); `red` is a 16-float LDS array no one else is using
-__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
-    v = wave_sum(v);
-    if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) s += red[w];
-    return s;
-}
-
-// y = LayerNorm over the D values held one per thread (tid < D); g, b = this thread's gamma / beta (loaded by the caller
-// together with its other loads, so that they are not a round trip of their own behind the two block sums)
-__device__ __forceinline__ float block_layernorm(float v, bool act, int D, float eps, float g, float b,
-                                                 float (*red)[16], int tid) {
-    TXT_STAMP(8);
-    const float mean = block_sum(act ? v : 0.f, red[0], tid) / (float)D;
-    TXT_STAMP(9);
-    const float d = act ? v - mean : 0.f;
-    const float rstd = rsqrtf(block_sum(d * d, red[1], tid) / (float)D + eps);
-    return act ? d * rstd * g + b : 0.f;
-}
-
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_tb;
 
 template <int K32, bool FP8, int WPB>
@@ -395,10 +372,12 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
     __syncthreads();
     TXT_STAMP(5);
     if (!last_flag) return;
-    if (SPLIT) {
-        // the row's LayerNorm with 64 * WPB threads: wave wl takes the 64-column chunks wl, wl + WPB, ...  A chunk is what
-        // wave `chunk` of the 16-wave workgroup holds, and the sums are formed the same way (shuffle tree inside the
-        // chunk, then the 16 chunk sums in order), so the result is bit for bit that of the one-workgroup form
+    {
+        // The row's LayerNorm with 64 * WPB threads: wave wl takes the 64-column chunks wl, wl + WPB, ... (the 16-wave
+        // workgroup: chunk = wave).  The sums are formed the same way for every WPB -- shuffle tree inside a chunk, then the
+        // 16 chunk sums in order -- and every multiply-add is spelled out (no contraction), so the result does not depend
+        // on how many workgroups shared the unit.
+#pragma clang fp contract(off)
         constexpr int NCH = (D + 63) / 64, CPW = (NCH + WPB - 1) / WPB;
         float v[CPW], g[CPW], b[CPW];
         if (tid < 16) { red[0][tid] = 0.f; red[1][tid] = 0.f; }
@@ -409,6 +388,7 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
             v[j] = 0.f; g[j] = 0.f; b[j] = 0.f;
             if (ch < NCH && col < D) {
                 g[j] = a.g1[col]; b[j] = a.b1[col];
+                // all H partials are requested before the first add; summed in head order
                 float s = 0.f;
                 const float* pp = a.part + (size_t)m * H * D + col;
                 for (int h0 = 0; h0 < H; h0 += 12) {
@@ -421,6 +401,7 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
                 v[j] = s + (a.aob[col] + a.xin[(size_t)m * D + col]);
             }
         }
+        TXT_STAMP(8);
 #pragma unroll
         for (int j = 0; j < CPW; ++j) {
             const int ch = wl + j * WPB;
@@ -432,12 +413,14 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
 #pragma unroll
         for (int w = 0; w < 16; ++w) sm += red[0][w];
         const float mean = sm / (float)D;
+        TXT_STAMP(9);
         float d[CPW];
 #pragma unroll
         for (int j = 0; j < CPW; ++j) {
             const int ch = wl + j * WPB, col = ch * 64 + lane;
             d[j] = (ch < NCH && col < D) ? v[j] - mean : 0.f;
-            const float ws = wave_sum(d[j] * d[j]);
+            const float dd = d[j] * d[j];
+            const float ws = wave_sum(dd);
             if (ch < NCH && lane == 0) red[1][ch] = ws;
         }
         __syncthreads();
@@ -449,29 +432,10 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
         for (int j = 0; j < CPW; ++j) {
             const int ch = wl + j * WPB, col = ch * 64 + lane;
             if (ch < NCH && col < D) {
-                const float y = d[j] * rstd * g[j] + b[j];
+                const float y = __builtin_fmaf(d[j] * rstd, g[j], b[j]);
                 a.xs[(size_t)m * D + col] = y; a.xsb[(size_t)m * D + col] = f2bf(y);
             }
         }
-    } else {
-        const bool act = tid < D;
-        float v = 0.f, g = 0.f, b = 0.f;
-        if (act) {
-            g = a.g1[tid]; b = a.b1[tid];
-            // all H partials are requested before the first add; summed in head order
-            float s = 0.f;
-            const float* pp = a.part + (size_t)m * H * D + tid;
-            for (int h0 = 0; h0 < H; h0 += 12) {
-                float p[12];
-#pragma unroll
-                for (int h = 0; h < 12; ++h) p[h] = (h0 + h < H) ? __hip_atomic_load(pp + (size_t)(h0 + h) * D, RLX_AGENT) : 0.f;
-#pragma unroll
-                for (int h = 0; h < 12; ++h) s += p[h];
-            }
-            v = s + (a.aob[tid] + a.xin[(size_t)m * D + tid]);
-        }
-        const float y = block_layernorm(v, act, D, a.eps, g, b, red, tid);
-        if (act) { a.xs[(size_t)m * D + tid] = y; a.xsb[(size_t)m * D + tid] = f2bf(y); }
     }
     TXT_STAMP(6);
 }
