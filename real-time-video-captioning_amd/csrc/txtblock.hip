@@ -35,14 +35,18 @@ namespace {
 constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Every multiply-add of the softmax arithmetic is spelled out (contraction off): the kernel is instantiated for several
+// workgroup sizes (key split), and the instantiations must round identically -- a contraction the compiler chose for one of
+// them and not for another moved a context value across a bf16 rounding boundary once in ~100 launches.
 struct Part { float m, l; float o[8]; };
 __device__ __forceinline__ void merge(Part& a, float m2, float l2, const float* o2) {
+#pragma clang fp contract(off)
     const float M = fmaxf(a.m, m2);
     const float s1 = (a.m == -INFINITY) ? 0.f : ex2(a.m - M);
     const float s2 = (m2 == -INFINITY) ? 0.f : ex2(m2 - M);
-    a.l = a.l * s1 + l2 * s2;
+    a.l = __builtin_fmaf(a.l, s1, l2 * s2);
 #pragma unroll
-    for (int d = 0; d < 8; ++d) a.o[d] = a.o[d] * s1 + o2[d] * s2;
+    for (int d = 0; d < 8; ++d) a.o[d] = __builtin_fmaf(a.o[d], s1, o2[d] * s2);
     a.m = M;
 }
 
@@ -149,12 +153,13 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
         }
     };
     auto reduce_group = [&](const bf16x8* kf, const bf16x8* vf, const bool* valid) {
+#pragma clang fp contract(off)
         float sc[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             float s = 0.f;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) s += qv[d] * bf2f((bf16_t)kf[u][d]);
+            for (int d = 0; d < 8; ++d) s = __builtin_fmaf(qv[d], bf2f((bf16_t)kf[u][d]), s);
             s += __shfl_xor(s, 1);
             s += __shfl_xor(s, 2);
             s += __shfl_xor(s, 4);
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
                 st.l += p;
                 const float pb = bf2f(f2bf(p));                 // P enters the PV product as bf16 (same rule as the MFMA path)
 #pragma unroll
-                for (int d = 0; d < 8; ++d) st.o[d] += pb * bf2f((bf16_t)vf[u][d]);
+                for (int d = 0; d < 8; ++d) st.o[d] = __builtin_fmaf(pb, bf2f((bf16_t)vf[u][d]), st.o[d]);
             }
             st.m = m_new;
         }
@@ -278,6 +283,7 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
         __syncthreads();
     }
     if (tid < 8) {
+#pragma clang fp contract(off)
         Part t;
         t.m = wsm[0][tid][0]; t.l = wsm[0][tid][1];
 #pragma unroll
