@@ -112,14 +112,12 @@ struct gitcap {
         // text-row workspace of the slot (token loops of different slots may run concurrently)
         float *xs = nullptr, *xs2 = nullptr, *slabs = nullptr, *part = nullptr, *amax_val = nullptr; int* amax_idx = nullptr;
         unsigned* row_cnt = nullptr;
-        float* kpart = nullptr; unsigned* kcnt = nullptr;      // key-split scratch of the text attention (small row counts)
         bf16_t *xsb = nullptr, *fs = nullptr, *kv_txt = nullptr, *kv_txt2 = nullptr;
         int B = 0, S = 0; bool have = false, used = false;
         hipEvent_t ev_in = nullptr, ev_enc = nullptr, ev_dec = nullptr;
         hipStream_t s_txt = nullptr;
     };
     static constexpr int NSLOT = 4;
-    static constexpr int KS_ROWS = 10;      // the text attention splits the keys of a unit over several workgroups up to this many rows
     Slot slots[NSLOT];
     int cur_slot = 0, next_ticket = 0;
     hipStream_t s_enc = nullptr;
@@ -471,8 +469,6 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
             ta.rows = rows; ta.beams = beams; ta.t0 = t0; ta.T = T; ta.Tmax = h->Tmax; ta.S_img = h->cur_S; ta.H = H; ta.D = D;
             ta.aow = L.aow.p; ta.aoscale = L.aow.scale; ta.aob = L.aob; ta.g1 = L.ln1w; ta.b1 = L.ln1b; ta.xin = xcur; ta.eps = c.dec_ln_eps;
             ta.part = h->part; ta.cnt = h->row_cnt; ta.xs = xcur; ta.xsb = h->xsb;
-            ta.kpart = h->slots[h->cur_slot].kpart; ta.kcnt = h->slots[h->cur_slot].kcnt; ta.kpart_rows = gitcap::KS_ROWS;
-            ta.kpart_bytes = gitcap::KS_ROWS * H * 16 * 8 * 12 * 4;
             double kvb = 0;
             for (int j = 0; j < T; ++j) kvb += (double)rows * (h->cur_S + t0 + j + 1) * 2 * D * 2;
             ProfScope ps(h, GITCAP_PROF_ATTN_TEXT, s, 0.0, kvb + (L.aow.scale ? 1.0 : 2.0) * D * D);     // K/V read once + the output dense
@@ -586,8 +582,6 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
         rc = rc ? rc : ws_alloc(h, &sl.xsb, Mt * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.part, Mt * (size_t)c.dec_heads * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.row_cnt, Mt);
-        rc = rc ? rc : ws_alloc(h, &sl.kpart, (size_t)gitcap::KS_ROWS * c.dec_heads * 16 * 8 * 12);
-        rc = rc ? rc : ws_alloc(h, &sl.kcnt, (size_t)gitcap::KS_ROWS * c.dec_heads);
         rc = rc ? rc : ws_alloc(h, &sl.fs, Mt * c.dec_ffn);
         rc = rc ? rc : ws_alloc(h, &sl.amax_val, Mt * (size_t)((h->V + 15) / 16));
         rc = rc ? rc : ws_alloc(h, &sl.amax_idx, Mt * (size_t)((h->V + 15) / 16));
@@ -1136,8 +1130,7 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
 
 // Speed-only switches at run time (the same ones the GITCAP_* environment variables set once per process): lets ONE process
 // check that results do not depend on them.  key 0: GEMM + LayerNorm epilogue on/off, 1: one/two-row prologue on/off,
-// 2: 256-tile threshold (GITCAP_GEMM_SMALL_TILES), 3: 128-tile threshold (GITCAP_GEMM_TINY_TILES), 4: 224-row tiles on/off,
-// 5: key split of the text attention for small row counts on/off.
+// 2: 256-tile threshold (GITCAP_GEMM_SMALL_TILES), 3: 128-tile threshold (GITCAP_GEMM_TINY_TILES), 4: 224-row tiles on/off.
 // Returns the old value.
 int gitcap_dbg_config(int key, int value) {
     int old = -1;
@@ -1147,7 +1140,6 @@ int gitcap_dbg_config(int key, int value) {
         case 2: old = g_small_tiles.exchange(value); break;
         case 3: old = g_tiny_tiles.exchange(value); break;
         case 4: old = g_tile224.exchange(value != 0); break;
-        case 5: old = g_key_split.exchange(value != 0); break;
         default: return GITCAP_ERR_ARG;
     }
     return old;

@@ -107,14 +107,9 @@ struct TxtBlockArgs {
     float* part;                                // [M][H][D] fp32 per-head partials of the output dense
     unsigned* cnt;                              // [M] arrival tickets (zero between launches)
     float* xs; bf16_t* xsb;                     // out: x1 [M][D] fp32 and bf16 (xs may alias xin)
-    // key split (small row counts; nullable = never split): per unit [16 waves][8][12] fp32 partial attention states and a
-    // ticket per unit (zero between launches)
-    float* kpart; unsigned* kcnt; int kpart_rows; int kpart_bytes;
     int Mh;                                     // set by the launcher
 };
 bool txt_block_ok(int D);
-extern std::atomic<bool> g_key_split;                                         // txtblock.hip: GITCAP_NO_KEY_SPLIT / gitcap_dbg_config(5, .)
-int txt_block_split(int M, int H, bool have_scratch, int scratch_rows);      // workgroups per (row, head) unit the launcher will use
 hipError_t launch_txt_block(const TxtBlockArgs& a, hipStream_t s);
 
 // Small attention of the student decoder (student.hip): one wave per (query row, head), at most 64 keys,

@@ -16,28 +16,24 @@
 // is an agent-scope (sc1) store, every storing wave drains vmcnt before the workgroup barrier, ONE lane adds the ticket,
 // the reducer's loads are agent-scope (sc1) loads issued after the barrier its ticket lane joined.  No spin anywhere.
 //
-// Small batches (the webcam case: one clip = 12 units on 256 CUs, each streaming 300 KB of K/V through ONE CU: 16 us per
-// launch, a third of the single-clip caption): KEY SPLIT.  The 16 waves of a unit are dealt to S = 2 .. 16 workgroups of
-// WPB = 16 / S waves; every wave does exactly the work it does in the 16-wave workgroup (same key groups, same order), the
-// per-wave partial states (m, l, o[64]) go to global memory (write-through), and the LAST of a unit's S workgroups to
-// arrive (ticket, nobody waits) merges the 16 partials in wave order -- the arithmetic of the one-workgroup form, so
-// the result is bit for bit the same whatever S is -- and carries on with the output dense, the row ticket and the
-// LayerNorm.  S is chosen from the row count (units x S <= 256 workgroups), so batch invariance is preserved.
-//
 // Why the q|k|v projection is NOT in here (measured, tools/probe/txtblock_probe.hip): a CU pulls weight fragments at
 // ~30 GB/s whatever serves them (HBM, Infinity Cache or L2); 295 KB of q|k|v weights per (row, head) unit cost 10 us in
 // front of the attention, against 6 us for a launch of single-wave tiles that reads every weight byte once.
 #include "kernels.h"
-#include "host_logic.h"
 
 namespace {
 
 constexpr float kScaleLog2e = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// Every multiply-add of the softmax arithmetic is spelled out (contraction off): the kernel is instantiated for several
-// workgroup sizes (key split), and the instantiations must round identically -- a contraction the compiler chose for one of
-// them and not for another moved a context value across a bf16 rounding boundary once in ~100 launches.
+// Every multiply-add of the softmax arithmetic is spelled out (contraction off), so the rounding does not depend on what the
+// compiler chooses to fuse in a given instantiation or compiler version.  (Round 3 built a key-split form of this kernel
+// for small row counts -- the 16 waves of a unit dealt to 2-8 workgroups, per-wave partial states merged by the last
+// arriver in wave order, bit for bit the same -- and found (a) that two instantiations of the SAME source had been
+// contracted differently, one context value crossing a bf16 rounding boundary once in ~100 launches, hence this; and
+// (b) no gain: one clip, 20 tokens 5.95 / 7.44 ms with 4 / 8 workgroups per unit against 5.87 ms, the last arriver's
+// serial tail -- gather, unprefetched output-dense weights, tickets -- costs what the shorter K/V stream saves;
+// profiles/r03_text_attention_key_split_latency.txt.  Removed.)
 struct Part { float m, l; float o[8]; };
 __device__ __forceinline__ void merge(Part& a, float m2, float l2, const float* o2) {
 #pragma clang fp contract(off)
@@ -60,34 +56,49 @@ __device__ unsigned long long* g_txt_stamps;
 #define TXT_STAMP(i) do {} while (0)
 #endif
 
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4_tb;
+// sum over the 16 waves of the block (fixed order); `red` is a 16-float LDS array no one else is using
+__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w];
+    return s;
+}
 
-template <int K32, bool FP8, int WPB>
-__global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
+// y = LayerNorm over the D values held one per thread (tid < D); g, b = this thread's gamma / beta (loaded by the caller
+// together with its other loads, so that they are not a round trip of their own behind the two block sums)
+__device__ __forceinline__ float block_layernorm(float v, bool act, int D, float eps, float g, float b,
+                                                 float (*red)[16], int tid) {
+#pragma clang fp contract(off)
+    TXT_STAMP(8);
+    const float mean = block_sum(act ? v : 0.f, red[0], tid) / (float)D;
+    TXT_STAMP(9);
+    const float d = act ? v - mean : 0.f;
+    const float rstd = rsqrtf(block_sum(d * d, red[1], tid) / (float)D + eps);
+    return act ? __builtin_fmaf(d * rstd, g, b) : 0.f;
+}
+
+template <int K32, bool FP8>
+__global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
     constexpr int D = K32 * 32;
-    constexpr int S = 16 / WPB;                    // workgroups per (row, head) unit
-    constexpr bool SPLIT = WPB < 16;
     __shared__ __attribute__((aligned(16))) bf16_t ctxs[64];
     __shared__ float red[2][16];
-    __shared__ __attribute__((aligned(16))) float wsm[16][8][12];      // per wave and 8-column group: m, l, o[8] (+ 2 pad)
+    __shared__ float wsm[16][8][10];
     __shared__ int last_flag;
     // per wave 8 KiB: the wave's first 32-key group (K 4 KiB | V 4 KiB) by LDS-DMA, then reused for the wave's
     // output-dense weight fragments
-    __shared__ __attribute__((aligned(16))) char kvpre[WPB * 8192];
+    __shared__ __attribute__((aligned(16))) char kvpre[16 * 8192];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wl = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave inside this workgroup
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = a.rows * a.T, H = a.H;
     // unit -> (m, head).  H == 12: blocks that share an XCD (blockIdx % 8 equal) take whole heads (8 heads on 8 XCDs,
     // heads 8..11 as half-heads of Mh | M - Mh rows), so a head's output-dense slice stays in ONE L2 and the beams of a
     // clip (same image K/V) meet there too.  Placement only affects speed.
-    int m, head, split = 0;
-    if (SPLIT) {
-        split = blockIdx.x % S;
-        const int unit = blockIdx.x / S;
-        m = unit / H; head = unit - m * H;
-        if (m >= M) return;
-    } else if (H == 12) {
+    int m, head;
+    if (H == 12) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         if (slot < M) { m = slot; head = xcd; }
         else {
@@ -100,7 +111,6 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
         m = blockIdx.x / H; head = blockIdx.x - m * H;
         if (m >= M) return;
     }
-    const int wid = split * WPB + wl;              // this wave's place among the unit's 16: decides its key groups
     const int r = m / a.T, j = m - r * a.T;
     const int clip = r / a.beams;
     const int ld = 3 * D;
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
     const int sub = lane & 7, kk = lane >> 3;
     const bf16_t* img = a.kv_img + (size_t)clip * a.S_img * ld + D + head * 64 + sub * 8;
     const bf16_t* txt = a.kv_txt + (size_t)r * a.Tmax * ld + D + head * 64 + sub * 8;
-    char* mypre = kvpre + wl * 8192;
+    char* mypre = kvpre + wid * 8192;
     // group 0 of this wave (keys 32 wid .. +31) -> LDS, lane-linear (lane = kk*8 + sub, one 1-KiB piece per 8 keys)
     auto dma_group0 = [&]() {
 #pragma unroll
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
             reduce_group(kA, vA, okA);                                     // (waits for the LDS reads)
             // the wave's 8 KiB are free again: its out-projection weight fragments arrive under the rest of the attention
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (!SPLIT) dma_out_weights();
+            dma_out_weights();
             g += 512;
             while (g < Lk) {                                               // kB holds group g
                 load_group(g + 512, kA, vA, okA);
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
                 reduce_group(kA, vA, okA);
                 g += 512;
             }
-        } else if (!SPLIT) {
+        } else {
             dma_out_weights();
         }
     }
@@ -245,43 +255,12 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
         for (int d = 0; d < 8; ++d) o2[d] = __shfl_xor(st.o[d], off);
         merge(st, m2, l2, o2);
     }
-    if (!SPLIT) {
-        if (kk == 0) {
-            wsm[wid][sub][0] = st.m; wsm[wid][sub][1] = st.l;
+    if (kk == 0) {
+        wsm[wid][sub][0] = st.m; wsm[wid][sub][1] = st.l;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) wsm[wid][sub][2 + d] = st.o[d];
-        }
-        __syncthreads();
-    } else {
-        // this wave's partial state -> the unit's scratch [16 waves][8][12 floats]: three 16-byte write-through stores per
-        // lane; every storing wave drains, the workgroup meets, ONE lane takes the ticket (Guideline 16 / "Valid forms")
-        const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)a.kpart, 0, a.kpart_bytes, 0x00020000);
-        const int ubase = ((m * H + head) * 16) * 8 * 12 * 4;             // bytes
-        if (kk == 0) {
-            const int off = ubase + (wid * 8 + sub) * 48;
-            const f32x4 v0 = {st.m, st.l, st.o[0], st.o[1]}, v1 = {st.o[2], st.o[3], st.o[4], st.o[5]}, v2 = {st.o[6], st.o[7], 0.f, 0.f};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_tb, v0), krs, off, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_tb, v1), krs, off + 16, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_tb, v2), krs, off + 32, 0, 16);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(a.kcnt + m * H + head, 1u, RLX_AGENT);
-            const int last = old == (unsigned)(S - 1);
-            if (last) __hip_atomic_store(a.kcnt + m * H + head, 0u, RLX_AGENT);   // all S have arrived: ready for the next launch
-            last_flag = last;
-        }
-        __syncthreads();
-        if (!last_flag) return;
-        // the last arriver gathers the 16 partial states (6 KiB, write-through stored by their owners: sc1 loads)
-        for (int i = tid; i < 16 * 8 * 3; i += 64 * WPB) {
-            const u32x4_tb v = __builtin_amdgcn_raw_buffer_load_b128(krs, ubase + i * 16, 0, 16);
-            *(u32x4_tb*)((char*)&wsm[0][0][0] + i * 16) = v;
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __syncthreads();
+        for (int d = 0; d < 8; ++d) wsm[wid][sub][2 + d] = st.o[d];
     }
+    __syncthreads();
     if (tid < 8) {
 #pragma clang fp contract(off)
         Part t;
@@ -299,45 +278,7 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
     TXT_STAMP(3);
 
     // ---- 2: this head's share of the output dense ---------------------------------------------------------------
-    if (SPLIT) {
-        // the last arriver did not know it would be: no prefetched weights.  Tiles wl, wl + WPB, ... of the D/16; the
-        // fragments of up to CH tiles are requested together (one round trip), straight to registers
-        constexpr int CH = 12;
-        const bf16x8 c0 = *(const bf16x8*)(ctxs + fq * 8), c1 = *(const bf16x8*)(ctxs + 32 + fq * 8);
-        float* pp = a.part + ((size_t)m * H + head) * D;
-        for (int t0 = wl; t0 < D / 16; t0 += WPB * CH) {
-            bf16x8 w0[CH], w1[CH];
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int t = t0 + i * WPB;
-                if (t < D / 16) {
-                    if (FP8) {
-                        const unsigned char* wp = (const unsigned char*)a.aow + (size_t)(t * 16 + frow) * D + head * 64 + fq * 8;
-                        const float sc = a.aoscale[t * 16 + frow];
-                        w0[i] = fp8x8_to_bf16x8(*(const uint2*)wp, sc);
-                        w1[i] = fp8x8_to_bf16x8(*(const uint2*)(wp + 32), sc);
-                    } else {
-                        const bf16_t* wp = (const bf16_t*)a.aow + (size_t)(t * 16 + frow) * D + head * 64 + fq * 8;
-                        w0[i] = *(const bf16x8*)wp;
-                        w1[i] = *(const bf16x8*)(wp + 32);
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int t = t0 + i * WPB;
-                if (t < D / 16) {
-                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0[i], c0, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i], c1, acc, 0, 0, 0);
-                    if (frow == 0) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) __hip_atomic_store(pp + t * 16 + fq * 4 + e, acc[e], RLX_AGENT);
-                    }
-                }
-            }
-        }
-    } else {
+    {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the wave's own weight DMA (read by itself only)
         const bf16x8 c0 = *(const bf16x8*)(ctxs + fq * 8), c1 = *(const bf16x8*)(ctxs + 32 + fq * 8);
         float* pp = a.part + ((size_t)m * H + head) * D;
@@ -379,69 +320,24 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
     TXT_STAMP(5);
     if (!last_flag) return;
     {
-        // The row's LayerNorm with 64 * WPB threads: wave wl takes the 64-column chunks wl, wl + WPB, ... (the 16-wave
-        // workgroup: chunk = wave).  The sums are formed the same way for every WPB -- shuffle tree inside a chunk, then the
-        // 16 chunk sums in order -- and every multiply-add is spelled out (no contraction), so the result does not depend
-        // on how many workgroups shared the unit.
-#pragma clang fp contract(off)
-        constexpr int NCH = (D + 63) / 64, CPW = (NCH + WPB - 1) / WPB;
-        float v[CPW], g[CPW], b[CPW];
-        if (tid < 16) { red[0][tid] = 0.f; red[1][tid] = 0.f; }
-        __syncthreads();
+        const bool act = tid < D;
+        float v = 0.f, g = 0.f, b = 0.f;
+        if (act) {
+            g = a.g1[tid]; b = a.b1[tid];
+            // all H partials are requested before the first add; summed in head order
+            float s = 0.f;
+            const float* pp = a.part + (size_t)m * H * D + tid;
+            for (int h0 = 0; h0 < H; h0 += 12) {
+                float p[12];
 #pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            const int ch = wl + j * WPB, col = ch * 64 + lane;
-            v[j] = 0.f; g[j] = 0.f; b[j] = 0.f;
-            if (ch < NCH && col < D) {
-                g[j] = a.g1[col]; b[j] = a.b1[col];
-                // all H partials are requested before the first add; summed in head order
-                float s = 0.f;
-                const float* pp = a.part + (size_t)m * H * D + col;
-                for (int h0 = 0; h0 < H; h0 += 12) {
-                    float p[12];
+                for (int h = 0; h < 12; ++h) p[h] = (h0 + h < H) ? __hip_atomic_load(pp + (size_t)(h0 + h) * D, RLX_AGENT) : 0.f;
 #pragma unroll
-                    for (int h = 0; h < 12; ++h) p[h] = (h0 + h < H) ? __hip_atomic_load(pp + (size_t)(h0 + h) * D, RLX_AGENT) : 0.f;
-#pragma unroll
-                    for (int h = 0; h < 12; ++h) s += p[h];
-                }
-                v[j] = s + (a.aob[col] + a.xin[(size_t)m * D + col]);
+                for (int h = 0; h < 12; ++h) s += p[h];
             }
+            v = s + (a.aob[tid] + a.xin[(size_t)m * D + tid]);
         }
-        TXT_STAMP(8);
-#pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            const int ch = wl + j * WPB;
-            const float ws = wave_sum(v[j]);
-            if (ch < NCH && lane == 0) red[0][ch] = ws;
-        }
-        __syncthreads();
-        float sm = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) sm += red[0][w];
-        const float mean = sm / (float)D;
-        TXT_STAMP(9);
-        float d[CPW];
-#pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            const int ch = wl + j * WPB, col = ch * 64 + lane;
-            d[j] = (ch < NCH && col < D) ? v[j] - mean : 0.f;
-            const float dd = d[j] * d[j];
-            const float ws = wave_sum(dd);
-            if (ch < NCH && lane == 0) red[1][ch] = ws;
-        }
-        __syncthreads();
-        float sq = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) sq += red[1][w];
-        const float rstd = rsqrtf(sq / (float)D + a.eps);
-#pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            const int ch = wl + j * WPB, col = ch * 64 + lane;
-            if (ch < NCH && col < D) {
-                const float y = __builtin_fmaf(d[j] * rstd, g[j], b[j]);
-                a.xs[(size_t)m * D + col] = y; a.xsb[(size_t)m * D + col] = f2bf(y);
-            }
-        }
+        const float y = block_layernorm(v, act, D, a.eps, g, b, red, tid);
+        if (act) { a.xs[(size_t)m * D + tid] = y; a.xsb[(size_t)m * D + tid] = f2bf(y); }
     }
     TXT_STAMP(6);
 }
@@ -449,29 +345,6 @@ __global__ __launch_bounds__(64 * WPB) void txt_block_kernel(TxtBlockArgs a) {
 }  // namespace
 
 bool txt_block_ok(int D) { return D == 128 || D == 768; }
-
-// workgroups per unit for a launch of M rows x H heads: the largest power of two (<= 8: at least two waves stay together
-// for the last arriver's share) that keeps units x S within the 256 CUs; 1 = the 16-wave workgroup.  Needs the scratch.
-std::atomic<bool> g_key_split{!env_flag("GITCAP_NO_KEY_SPLIT")};      // gitcap_dbg_config(5, .)
-
-int txt_block_split(int M, int H, bool have_scratch, int scratch_rows) {
-    if (!g_key_split || !have_scratch || M > scratch_rows) return 1;
-    int S = 1;
-    while (S < 8 && M * H * S * 2 <= 256) S *= 2;
-    return S;
-}
-
-template <int K32, bool FP8>
-static hipError_t launch_split(const TxtBlockArgs& a, int S, int grid1, hipStream_t s) {
-    const int M = a.rows * a.T;
-    switch (S) {
-        case 8: hipLaunchKernelGGL((txt_block_kernel<K32, FP8, 2>), dim3(M * a.H * 8), dim3(128), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((txt_block_kernel<K32, FP8, 4>), dim3(M * a.H * 4), dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((txt_block_kernel<K32, FP8, 8>), dim3(M * a.H * 2), dim3(512), 0, s, a); break;
-        default: hipLaunchKernelGGL((txt_block_kernel<K32, FP8, 16>), dim3(grid1), dim3(1024), 0, s, a); break;
-    }
-    return hipGetLastError();
-}
 
 hipError_t launch_txt_block(const TxtBlockArgs& a_in, hipStream_t s) {
     TxtBlockArgs a = a_in;
@@ -481,13 +354,13 @@ hipError_t launch_txt_block(const TxtBlockArgs& a_in, hipStream_t s) {
     const int unit = a.T == 1 ? a.beams : 1;
     a.Mh = ((M / unit + 1) / 2) * unit;
     const int grid = a.H == 12 ? 8 * (M + (a.Mh > M - a.Mh ? a.Mh : M - a.Mh)) : M * a.H;
-    const int S = txt_block_split(M, a.H, a.kpart != nullptr && a.kcnt != nullptr, a.kpart_rows);
     const int key = a.D * 2 + (a.aoscale ? 1 : 0);
     switch (key) {
-        case 256: return launch_split<4, false>(a, S, grid, s);
-        case 257: return launch_split<4, true>(a, S, grid, s);
-        case 1536: return launch_split<24, false>(a, S, grid, s);
-        case 1537: return launch_split<24, true>(a, S, grid, s);
+        case 256: hipLaunchKernelGGL((txt_block_kernel<4, false>), dim3(grid), dim3(1024), 0, s, a); break;
+        case 257: hipLaunchKernelGGL((txt_block_kernel<4, true>), dim3(grid), dim3(1024), 0, s, a); break;
+        case 1536: hipLaunchKernelGGL((txt_block_kernel<24, false>), dim3(grid), dim3(1024), 0, s, a); break;
+        case 1537: hipLaunchKernelGGL((txt_block_kernel<24, true>), dim3(grid), dim3(1024), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
 }

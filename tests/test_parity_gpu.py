@@ -184,7 +184,7 @@ def test_results_do_not_depend_on_speed_switches(captioner_cls):
         return vis.clone(), ids.clone(), m.forward_decoder(ids[:, :-1], vis).clone()
     base8, base1 = run(8), run(1)
     assert torch.equal(base1[1], base8[1][:1]) and torch.equal(base1[0], base8[0][:1])
-    settings = [(0, 0), (1, 0), (2, 1 << 30), (3, 0), (3, 1 << 30), (2, 1), (4, 0), (5, 0)]   # (key, value); (2, 1): 256-tile kernels even for one clip; (4, 0): no 224-row tiles; (5, 0): no key split of the text attention
+    settings = [(0, 0), (1, 0), (2, 1 << 30), (3, 0), (3, 1 << 30), (2, 1), (4, 0)]   # (key, value); (2, 1): 256-tile kernels even for one clip; (4, 0): no 224-row tiles
     for key, value in settings:
         old = lib.gitcap_dbg_config(key, value)
         assert old >= 0
@@ -677,36 +677,3 @@ def test_forward_output_logits_hidden_states(captioner_cls, golden_dir):
     l2, _, h2 = m.forward_output_logits(fr, ids)
     assert h2 == [] and torch.equal(torch.cat(l2), torch.cat(logits))
     assert torch.equal(m.greedy_decode(fr, max_len=6, stop="never"), captioner_cls(cfg, w, max_batch=2, max_text_len=8).greedy_decode(fr, max_len=6, stop="never"))
-
-
-def test_text_attention_key_split_is_bitwise_neutral(captioner_cls):
-    """Small row counts split the keys of every (row, head) unit of the text attention over 2-8 workgroups (txtblock.hip); the
-    last to arrive merges the per-wave partial states in the order of the one-workgroup form.  For every split factor the
-    greedy ids, the cached step logits and a teacher-forced pass must equal the unsplit kernel's bit for bit (the factor
-    follows the row count, so anything else would break batch invariance)."""
-    from gitcap import _lib
-    lib = _lib.load()
-    cfg = git_base(2)
-    w = synthetic_weights(cfg, 5)
-    m = captioner_cls(cfg, w, max_batch=11, max_frames=2, max_text_len=8)
-    fr = make_frames(11, 2, cfg.image_size, 29).cuda()
-    full = m.greedy_decode(fr, max_len=8, stop="never")                   # 11 rows: one workgroup per unit
-    for B in (1, 2, 3, 5, 6, 10):                                          # 8, 8, 4, 4, 2, 2 workgroups per unit
-        ids = m.greedy_decode(fr[:B], max_len=8, stop="never")
-        assert torch.equal(ids, full[:B]), B
-        step = m.step_logits(ids[:, 3], 3).clone()                          # image K/V of fr[:B] are in the handle
-        old = lib.gitcap_dbg_config(5, 0)
-        try:
-            assert torch.equal(m.greedy_decode(fr[:B], max_len=8, stop="never"), ids), B
-            assert torch.equal(m.step_logits(ids[:, 3], 3), step), B
-        finally:
-            lib.gitcap_dbg_config(5, old)
-    # a single row teacher-forced over 5 positions = 5 text rows at different lengths (4 workgroups per unit)
-    _, vis = m.forward_image_enc(fr[:1])
-    tf = m.forward_decoder(full[:1, :5], vis).clone()
-    old = lib.gitcap_dbg_config(5, 0)
-    try:
-        assert torch.equal(m.forward_decoder(full[:1, :5], vis), tf)
-    finally:
-        lib.gitcap_dbg_config(5, old)
-    assert torch.equal(tf.argmax(-1), full[:1, 1:6])
