@@ -469,22 +469,12 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
             ta.rows = rows; ta.beams = beams; ta.t0 = t0; ta.T = T; ta.Tmax = h->Tmax; ta.S_img = h->cur_S; ta.H = H; ta.D = D;
             ta.aow = L.aow.p; ta.aoscale = L.aow.scale; ta.aob = L.aob; ta.g1 = L.ln1w; ta.b1 = L.ln1b; ta.xin = xcur; ta.eps = c.dec_ln_eps;
             ta.part = h->part; ta.cnt = h->row_cnt; ta.xs = xcur; ta.xsb = h->xsb;
-            ta.defer_ln = rows_pro ? 1 : 0;             // one or two rows: the FC1 launch below closes the sub-layer itself
             double kvb = 0;
             for (int j = 0; j < T; ++j) kvb += (double)rows * (h->cur_S + t0 + j + 1) * 2 * D * 2;
             ProfScope ps(h, GITCAP_PROF_ATTN_TEXT, s, 0.0, kvb + (L.aow.scale ? 1.0 : 2.0) * D * D);     // K/V read once + the output dense
             HIP_OK(h, launch_txt_block(ta, s));
         }
-        if (rows_pro) {
-            // FC1 with the row prologue: x1 = LayerNorm(sum of the H per-head partials of the output dense + bias + x) is computed by
-            // every workgroup while its weight fragments are in flight; workgroup 0 writes the fp32 row(s) to the other buffer
-            ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * M * c.dec_ffn * D, 2.0 * c.dec_ffn * D);
-            SkinnyArgs a{h->xsb, D, L.fc1w.p, nullptr, L.fc1b, M, c.dec_ffn, D, h->fs, c.dec_ffn, 1, 1, 0, nullptr, nullptr};
-            a.ln.kind = 1; a.ln.slabs = h->part; a.ln.nslab = H; a.ln.bias = L.aob; a.ln.resid = xcur; a.ln.g = L.ln1w; a.ln.b = L.ln1b;
-            a.ln.eps = c.dec_ln_eps; a.ln.xf = xalt;
-            HIP_OK(h, launch_skinny(a, SK_BIAS_GELU_BF16, s));
-            std::swap(xcur, xalt);
-        } else if ((rc = skinny(h, s, SK_BIAS_GELU_BF16, h->xsb, D, L.fc1w, L.fc1b, M, c.dec_ffn, D, h->fs, c.dec_ffn))) return rc;
+        if ((rc = skinny(h, s, SK_BIAS_GELU_BF16, h->xsb, D, L.fc1w, L.fc1b, M, c.dec_ffn, D, h->fs, c.dec_ffn))) return rc;
         if ((rc = skinny_splitk(h, s, h->fs, c.dec_ffn, L.fc2w, M, D, c.dec_ffn, h->slabs))) return rc;
     }
     {   // the last layer's FC2 reduce + bias + residual + LayerNorm

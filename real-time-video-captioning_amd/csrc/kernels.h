@@ -104,8 +104,7 @@ struct TxtBlockArgs {
     const float *aob, *g1, *b1;                 // its bias; LayerNorm of the sub-layer
     const float* xin;                           // [M][D] the sub-layer's input (residual)
     float eps;
-    float* part;                                // [H][M][D] fp32 per-head partials of the output dense (slab layout of rowln.h)
-    int defer_ln;                               // 1: stop after the partials; the FC1 launch's row prologue reduces + normalises (M <= 2)
+    float* part;                                // [M][H][D] fp32 per-head partials of the output dense
     unsigned* cnt;                              // [M] arrival tickets (zero between launches)
     float* xs; bf16_t* xsb;                     // out: x1 [M][D] fp32 and bf16 (xs may alias xin)
     int Mh;                                     // set by the launcher

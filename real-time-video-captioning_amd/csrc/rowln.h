@@ -1,8 +1,7 @@
 // Row LayerNorm of the text rows, shared by the stand-alone row kernels (rowops.hip) and by the q|k|v projection that
 // computes its own input rows when there are only one or two of them (skinny.hip, "row prologue"): ONE wave per row, lane
 // holds NV float4 at columns 256 i + 4 lane, two-pass (mean, then centred variance) in registers, fp32 throughout.
-// The same inline code wherever a row is normalised, and every multiply-add spelled out (contraction off), so the result does
-// not depend on which kernel ran it nor on what the compiler would fuse in that kernel's context.
+// The same inline code wherever a row is normalised, so the result does not depend on which kernel ran it.
 #pragma once
 #include "common.h"
 
@@ -10,7 +9,6 @@
 template <int NV>
 __device__ __forceinline__ void row_layernorm(f32x4 (&v)[NV], const float s, const int lane, const int D, const float eps,
                                               const float* __restrict__ gamma, const float* __restrict__ beta) {
-#pragma clang fp contract(off)
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
@@ -18,7 +16,7 @@ __device__ __forceinline__ void row_layernorm(f32x4 (&v)[NV], const float s, con
         const int c = i * 256 + lane * 4;
         if (c < D) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q = __builtin_fmaf(d, d, q); }
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
@@ -29,26 +27,16 @@ __device__ __forceinline__ void row_layernorm(f32x4 (&v)[NV], const float s, con
             const f32x4 g = *(const f32x4*)(gamma + c);
             const f32x4 b = *(const f32x4*)(beta + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[i][e] = __builtin_fmaf((v[i][e] - mean) * rstd, g[e], b[e]);
+            for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * g[e] + b[e];
         }
     }
 }
 
-// v = sum_k slab[k][m] (fixed order) + bias + resid[m]; returns the lane-sum.  SC1: the slabs were written (write-through)
-// by other workgroups of the SAME launch and are read with agent-scope loads (txtblock.hip's last arriver); otherwise they
-// come from an earlier launch and plain loads do.
-template <int NV, bool SC1 = false>
+// v = sum_k slab[k][m] (fixed order) + bias + resid[m]; returns the lane-sum
+template <int NV>
 __device__ __forceinline__ float row_load_reduce(f32x4 (&v)[NV], const float* __restrict__ slabs, const int nslab,
                                                  const float* __restrict__ bias, const float* __restrict__ resid,
                                                  const int M, const int D, const int m, const int lane) {
-#pragma clang fp contract(off)
-    // (SC1: one buffer resource over the wave-uniform slab base, per-lane byte offsets)
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_rl;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slabs, 0, SC1 ? nslab * M * D * 4 : 0, 0x00020000);
-    auto ld = [&](const size_t elem) -> f32x4 {
-        if (SC1) return __builtin_bit_cast(f32x4, (u32x4_rl)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)(elem * 4), 0, 16));
-        return *(const f32x4*)(slabs + elem);
-    };
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // 8 slabs x NV vectors are requested before the first add (no serial latency chain); the
@@ -60,7 +48,8 @@ __device__ __forceinline__ float row_load_reduce(f32x4 (&v)[NV], const float* __
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int c = i * 256 + lane * 4;
-                p[k][i] = (k0 + k < nslab && c < D) ? ld(((size_t)(k0 + k) * M + m) * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                p[k][i] = (k0 + k < nslab && c < D) ? *(const f32x4*)(slabs + ((size_t)(k0 + k) * M + m) * D + c)
+                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
         for (int i = 0; i < NV; ++i)

@@ -191,7 +191,7 @@ hipError_t launch_full(const SkinnyArgs& a, int epi, hipStream_t s) {
     return hipGetLastError();
 }
 
-// with the row prologue: a bf16-output projection of one or two text rows (GIT q|k|v and FC1; the student's q|k|v, cross q, FC1)
+// with the row prologue: a bf16-output projection of one or two text rows (GIT q|k|v; the student's q|k|v, cross q, FC1)
 template <int K32>
 hipError_t launch_full_rows(const SkinnyArgs& a, int epi, hipStream_t s) {
     const SkinnyArgs::RowPrologue& p = a.ln;
@@ -202,7 +202,6 @@ hipError_t launch_full_rows(const SkinnyArgs& a, int epi, hipStream_t s) {
     const dim3 grid((a.N + 15) / 16);
     if (epi == SK_BIAS_BF16) hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16, false, true>), grid, dim3(64), 0, s, a);
     else if (epi == SK_BIAS_RELU_BF16) hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_RELU_BF16, false, true>), grid, dim3(64), 0, s, a);
-    else if (epi == SK_BIAS_GELU_BF16) hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_GELU_BF16, false, true>), grid, dim3(64), 0, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

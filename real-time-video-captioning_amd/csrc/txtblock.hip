@@ -10,8 +10,7 @@
 //   2. this head's share of the output dense: ctx_h[64] . Wo[:, 64h:64h+64]^T -> part[m][head][D] (fp32, write-through);
 //      the 6 KiB of weight fragments a wave needs arrive by LDS-DMA under the attention
 //   3. the LAST of the H units of a row to arrive (ticket counter; no unit ever waits for another) sums the H partials
-//      in head order, adds bias + residual and applies LayerNorm (one wave, rowln.h) -> x1 (fp32) and bf16(x1) for the
-//      FC1 launch.  With one or two rows step 3 moves into the FC1 launch (defer_ln).
+//      in head order, adds bias + residual and applies LayerNorm -> x1 (fp32) and bf16(x1) for the FC1 launch.
 // This replaces three launches of the first version (attention, split-K output dense, reduce + LayerNorm) by one.
 // Hand-off in 3 follows cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms": every payload store
 // is an agent-scope (sc1) store, every storing wave drains vmcnt before the workgroup barrier, ONE lane adds the ticket,
@@ -21,7 +20,6 @@
 // ~30 GB/s whatever serves them (HBM, Infinity Cache or L2); 295 KB of q|k|v weights per (row, head) unit cost 10 us in
 // front of the attention, against 6 us for a launch of single-wave tiles that reads every weight byte once.
 #include "kernels.h"
-#include "rowln.h"
 
 namespace {
 
@@ -58,10 +56,35 @@ __device__ unsigned long long* g_txt_stamps;
 #define TXT_STAMP(i) do {} while (0)
 #endif
 
+// sum over the 16 waves of the block (fixed order); `red` is a 16-float LDS array no one else is using
+__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w];
+    return s;
+}
+
+// y = LayerNorm over the D values held one per thread (tid < D); g, b = this thread's gamma / beta (loaded by the caller
+// together with its other loads, so that they are not a round trip of their own behind the two block sums)
+__device__ __forceinline__ float block_layernorm(float v, bool act, int D, float eps, float g, float b,
+                                                 float (*red)[16], int tid) {
+#pragma clang fp contract(off)
+    TXT_STAMP(8);
+    const float mean = block_sum(act ? v : 0.f, red[0], tid) / (float)D;
+    TXT_STAMP(9);
+    const float d = act ? v - mean : 0.f;
+    const float rstd = rsqrtf(block_sum(d * d, red[1], tid) / (float)D + eps);
+    return act ? __builtin_fmaf(d * rstd, g, b) : 0.f;
+}
+
 template <int K32, bool FP8>
 __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
     constexpr int D = K32 * 32;
     __shared__ __attribute__((aligned(16))) bf16_t ctxs[64];
+    __shared__ float red[2][16];
     __shared__ float wsm[16][8][10];
     __shared__ int last_flag;
     // per wave 8 KiB: the wave's first 32-key group (K 4 KiB | V 4 KiB) by LDS-DMA, then reused for the wave's
@@ -258,7 +281,7 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
     {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the wave's own weight DMA (read by itself only)
         const bf16x8 c0 = *(const bf16x8*)(ctxs + fq * 8), c1 = *(const bf16x8*)(ctxs + 32 + fq * 8);
-        float* pp = a.part + ((size_t)head * M + m) * D;                   // [head][M][D]: the slab layout of rowln.h
+        float* pp = a.part + ((size_t)m * H + head) * D;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             const int t = wid + 16 * i;
@@ -284,11 +307,6 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
         }
     }
     // ---- 3: ticket; the last unit of the row reduces ---------------------------------------------------------------
-    // defer_ln (one or two rows): the kernel ends here; the FC1 launch behind it sums the H partials, adds bias + residual
-    // and normalises the row(s) itself while its weight fragments are in flight (skinny.hip row prologue) -- the same
-    // inline code (rowln.h) as the reducer below, so the same bits -- and the ticket, the reducer and their two global
-    // round trips drop out of the chain.
-    if (a.defer_ln) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // every storing wave, before the barrier
     __syncthreads();
     TXT_STAMP(4);
@@ -300,15 +318,26 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
     }
     __syncthreads();
     TXT_STAMP(5);
-    if (!last_flag || wid != 0) return;
-    {   // ONE wave normalises the row: sum of the H partials in head order + bias + residual -> LayerNorm (rowln.h, the
-        // code every other producer of a text row runs).  The partials were stored write-through by other workgroups of
-        // this launch: agent-scope (sc1) loads, issued after the barrier the ticket lane joined.
-        constexpr int NV = (D + 255) / 256;
-        f32x4 v[NV];
-        const float s = row_load_reduce<NV, true>(v, a.part, H, a.aob, a.xin, M, D, m, lane);
-        row_layernorm<NV>(v, s, lane, D, a.eps, a.g1, a.b1);
-        row_store<NV>(v, lane, D, a.xs + (size_t)m * D, a.xsb + (size_t)m * D);
+    if (!last_flag) return;
+    {
+        const bool act = tid < D;
+        float v = 0.f, g = 0.f, b = 0.f;
+        if (act) {
+            g = a.g1[tid]; b = a.b1[tid];
+            // all H partials are requested before the first add; summed in head order
+            float s = 0.f;
+            const float* pp = a.part + (size_t)m * H * D + tid;
+            for (int h0 = 0; h0 < H; h0 += 12) {
+                float p[12];
+#pragma unroll
+                for (int h = 0; h < 12; ++h) p[h] = (h0 + h < H) ? __hip_atomic_load(pp + (size_t)(h0 + h) * D, RLX_AGENT) : 0.f;
+#pragma unroll
+                for (int h = 0; h < 12; ++h) s += p[h];
+            }
+            v = s + (a.aob[tid] + a.xin[(size_t)m * D + tid]);
+        }
+        const float y = block_layernorm(v, act, D, a.eps, g, b, red, tid);
+        if (act) { a.xs[(size_t)m * D + tid] = y; a.xsb[(size_t)m * D + tid] = f2bf(y); }
     }
     TXT_STAMP(6);
 }
