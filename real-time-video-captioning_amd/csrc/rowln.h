@@ -1,7 +1,8 @@
 // Row LayerNorm of the text rows, shared by the stand-alone row kernels (rowops.hip) and by the q|k|v projection that
 // computes its own input rows when there are only one or two of them (skinny.hip, "row prologue"): ONE wave per row, lane
 // holds NV float4 at columns 256 i + 4 lane, two-pass (mean, then centred variance) in registers, fp32 throughout.
-// The same inline code wherever a row is normalised, so the result does not depend on which kernel ran it.
+// The same inline code wherever a row is normalised, and every multiply-add spelled out (contraction off), so the result does
+// not depend on which kernel ran it nor on what the compiler would fuse in that kernel's context.
 #pragma once
 #include "common.h"
 
@@ -9,6 +10,7 @@
 template <int NV>
 __device__ __forceinline__ void row_layernorm(f32x4 (&v)[NV], const float s, const int lane, const int D, const float eps,
                                               const float* __restrict__ gamma, const float* __restrict__ beta) {
+#pragma clang fp contract(off)
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
@@ -16,7 +18,7 @@ __device__ __forceinline__ void row_layernorm(f32x4 (&v)[NV], const float s, con
         const int c = i * 256 + lane * 4;
         if (c < D) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q = __builtin_fmaf(d, d, q); }
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
@@ -27,7 +29,7 @@ __device__ __forceinline__ void row_layernorm(f32x4 (&v)[NV], const float s, con
             const f32x4 g = *(const f32x4*)(gamma + c);
             const f32x4 b = *(const f32x4*)(beta + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[i][e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            for (int e = 0; e < 4; ++e) v[i][e] = __builtin_fmaf((v[i][e] - mean) * rstd, g[e], b[e]);
         }
     }
 }
