@@ -108,6 +108,7 @@ struct TxtBlockArgs {
     unsigned* cnt;                              // [M] arrival tickets (zero between launches)
     float* xs; bf16_t* xsb;                     // out: x1 [M][D] fp32 and bf16 (xs may alias xin)
     int Mh;                                     // set by the launcher
+    int nt_kv;                                  // 1: the K/V rows are streamed with non-temporal loads (they do not fit the caches anyway)
 };
 bool txt_block_ok(int D);
 hipError_t launch_txt_block(const TxtBlockArgs& a, hipStream_t s);

@@ -20,6 +20,7 @@
 // ~30 GB/s whatever serves them (HBM, Infinity Cache or L2); 295 KB of q|k|v weights per (row, head) unit cost 10 us in
 // front of the attention, against 6 us for a launch of single-wave tiles that reads every weight byte once.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -130,8 +131,13 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
             int key = wid * 32 + u * 8 + kk;
             key = key < Lk ? key : 0;
             const bf16_t* kp = key < a.S_img ? img + (size_t)key * ld : txt + (size_t)(key - a.S_img) * ld;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(kp), LDS_PTR(mypre + u * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(kp + D), LDS_PTR(mypre + 4096 + u * 1024), 16, 0, 0);
+            if (a.nt_kv) {
+                __builtin_amdgcn_global_load_lds(GLB_PTR(kp), LDS_PTR(mypre + u * 1024), 16, 0, 2);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(kp + D), LDS_PTR(mypre + 4096 + u * 1024), 16, 0, 2);
+            } else {
+                __builtin_amdgcn_global_load_lds(GLB_PTR(kp), LDS_PTR(mypre + u * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(kp + D), LDS_PTR(mypre + 4096 + u * 1024), 16, 0, 0);
+            }
         }
     };
     if (wid * 32 < Lk) dma_group0();
@@ -158,8 +164,13 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
             valid[u] = key < Lk;
             key = valid[u] ? key : 0;
             const bf16_t* kp = key < a.S_img ? img + (size_t)key * ld : txt + (size_t)(key - a.S_img) * ld;
-            kf[u] = *(const bf16x8*)kp;
-            vf[u] = *(const bf16x8*)(kp + D);
+            if (a.nt_kv) {      // read once per launch and too large to stay cached: do not displace what the GEMMs re-read
+                kf[u] = __builtin_nontemporal_load((const bf16x8*)kp);
+                vf[u] = __builtin_nontemporal_load((const bf16x8*)(kp + D));
+            } else {
+                kf[u] = *(const bf16x8*)kp;
+                vf[u] = *(const bf16x8*)(kp + D);
+            }
         }
     };
     auto reduce_group = [&](const bf16x8* kf, const bf16x8* vf, const bool* valid) {
@@ -348,6 +359,8 @@ bool txt_block_ok(int D) { return D == 128 || D == 768; }
 
 hipError_t launch_txt_block(const TxtBlockArgs& a_in, hipStream_t s) {
     TxtBlockArgs a = a_in;
+    static const int nt = getenv("GITCAP_TXT_NT") ? atoi(getenv("GITCAP_TXT_NT")) : -1;    // A/B switch: 0 never, 1 always
+    if (nt >= 0) a.nt_kv = nt;
     const int M = a.rows * a.T;
     if (M <= 0 || a.H * 64 != a.D || a.beams <= 0 || !a.xin) return hipErrorInvalidValue;
     // first "half" of the rows for heads 8..11 (H == 12 mapping): whole clips (all beams of a clip stay together)
