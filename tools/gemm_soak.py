@@ -1,4 +1,5 @@
-# race screen for gemm256 (hand-placed counted vmcnt / staggered barriers): many launches per shape, output
+# race screen for the big-tile GEMMs -- gemm256 (default) or, with argv[1] = 224 / 257, gemm_mt.hip on 224- / 256-row tiles
+# (hand-placed counted vmcnt / staggered barriers): many launches per shape, output
 # poisoned with NaN before every launch, every result compared with the fp32 reference; second pass with a
 # concurrent stream hammering HBM so that DMA arrival times vary
 import sys, ctypes, torch
@@ -7,9 +8,11 @@ from gitcap import _lib
 lib = _lib.load()
 dev = torch.device('cuda:0')
 p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+TILE = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 def soak(M, N, K, epi, tile, iters, noise):
     g = torch.Generator(device='cuda').manual_seed(M * 7 + N * 3 + K + epi)
-    A = torch.randn(M, K, device=dev, generator=g).bfloat16(); W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).bfloat16()
+    if tile == 224: M = (M + 223) // 224 * 224
+    A = torch.zeros(M + 16, K, device=dev, dtype=torch.bfloat16); A[:M] = torch.randn(M, K, device=dev, generator=g).bfloat16(); A = A[:M]; W = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).bfloat16()
     bias = torch.randn(N, device=dev, generator=g); resid = torch.randn(M, N, device=dev, generator=g) if epi == 3 else None
     out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi in (3, 4) else torch.bfloat16)
     ref = A.float() @ W.float().t() + bias
@@ -32,5 +35,5 @@ def soak(M, N, K, epi, tile, iters, noise):
     return worst, bad
 for noise in (False, True):
     for (M, N, K, epi) in [(18944, 768, 768, 3), (18944, 2304, 768, 0), (18944, 3072, 768, 1), (18944, 768, 3072, 3), (2560, 1536, 768, 0), (256, 256, 64, 4), (512, 256, 128, 4)]:
-        w, b = soak(M, N, K, epi, 256, 150 if M > 4000 else 400, noise)
+        w, b = soak(M, N, K, epi, TILE, 150 if M > 4000 else 400, noise)
         print('noise=%d M=%d N=%d K=%d epi=%d: worst err %.4g, bad launches %d' % (noise, M, N, K, epi, w, b), flush=True)
