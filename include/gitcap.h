@@ -222,7 +222,8 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
                        int fused, int tile, void* stream);
 /* Speed-only switches at run time (what the GITCAP_* environment variables set once per process; INTEGRATION.md par. 9), so that
  * one process can check that results do not depend on them.  key 0: GEMM + LayerNorm epilogue on/off; 1: one/two-row prologue
- * on/off; 2: 256x256-tile threshold; 3: 128x128-tile threshold; 4: 224-row tiles for synchronous calls on/off.  Returns the previous value (< 0: bad key).  The switches are process-wide atomics: a call on another thread sees either value,
+ * on/off; 2: 256x256-tile threshold; 3: 128x128-tile threshold; 4: 224-row tiles for synchronous calls on/off; 5: the greedy loop's
+ * arg-max launch also embeds the next step's input rows on/off.  Returns the previous value (< 0: bad key).  The switches are process-wide atomics: a call on another thread sees either value,
  * and either value gives the same bits. */
 int gitcap_dbg_config(int key, int value);
 /* attn_full: qkv [G*S][3*H*64] bf16 -> ctx [G*S][H*64] bf16 */

@@ -410,8 +410,20 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
     return 0;
 }
 
+// The greedy loop chains token steps: `pre_embedded` = the input rows of this step (embedding of the token at position t0 +
+// LayerNorm) were already produced by the previous step's arg-max launch; `embed_next` = this step's arg-max launch produces
+// the next step's.  Same row code either way (rowln.h); one launch less per token step.  Only with more than two rows (with
+// one or two the q|k|v launch embeds its rows itself) and one position per row.
+std::atomic<bool> g_chain_steps{!env_flag("GITCAP_NO_STEP_CHAIN")};       // gitcap_dbg_config(5, .)
+
+bool text_chain_ok(gitcap* h, int rows, int T) {
+    return g_chain_steps && T == 1 && !(h->want_hidden && h->cur_slot == 0) &&
+           !(g_row_prologue && skinny_row_prologue_ok(rows, h->D, h->dec[0].qkvw.scale != nullptr));
+}
+
 int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams, int t0, int T, float* logits_out,
-                 int all_positions, int64_t* argmax_out, int ld_argmax, int32_t* sep_cnt, int step, hipStream_t s) {
+                 int all_positions, int64_t* argmax_out, int ld_argmax, int32_t* sep_cnt, int step, hipStream_t s,
+                 bool pre_embedded = false, bool embed_next = false) {
     const gitcap_config& c = h->c;
     if (!h->finalized) return fail(h, GITCAP_ERR_STATE, "weights not finalized");
     if (!h->have_image) return fail(h, GITCAP_ERR_STATE, "text_forward before encode/set_visual");
@@ -454,8 +466,9 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
             std::swap(xcur, xalt);
         } else {
             if (l == 0) {
-                HIP_OK(h, launch_embed_text(ids, ld_ids, rows, T, t0, h->word, h->tpos, h->txt_lnw, h->txt_lnb, c.dec_ln_eps, D,
-                                            c.vocab_size, xcur, h->xsb, s));
+                if (!pre_embedded)
+                    HIP_OK(h, launch_embed_text(ids, ld_ids, rows, T, t0, h->word, h->tpos, h->txt_lnw, h->txt_lnb, c.dec_ln_eps, D,
+                                                c.vocab_size, xcur, h->xsb, s));
             } else {
                 const DecLayer& P = h->dec[l - 1];
                 if ((rc = ln_reduce(h, s, h->slabs, ks_f, P.fc2b, xcur, P.ln2w, P.ln2b, c.dec_ln_eps, M, D, xcur, h->xsb))) return rc;
@@ -503,9 +516,11 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
         ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * ha.M * V * D, (ha.wscale ? 1.0 : 2.0) * V * D);
         HIP_OK(h, launch_skinny(ha, SK_BIAS_F32, s));
     }
-    if (argmax_out)
+    if (argmax_out) {
+        const NextEmbed ne{h->word, h->tpos, h->txt_lnw, h->txt_lnb, c.dec_ln_eps, D, c.vocab_size, t0 + 1, h->xs, h->xsb};
         HIP_OK(h, launch_argmax_final(h->amax_val, h->amax_idx, ntiles, rows, am_stride, am_off, argmax_out, ld_argmax,
-                                      sep_cnt, step, c.sep_token_id, s));
+                                      sep_cnt, step, c.sep_token_id, s, embed_next ? &ne : nullptr));
+    }
     return 0;
 }
 
@@ -898,9 +913,11 @@ static int greedy_text_loop(gitcap* h, int B, int max_len, int stop, int64_t* id
     // CLS start tokens [B,1] (model.py:171)
     HIP_OK(h, launch_fill_i64(ids_out, ld, B, h->c.cls_token_id, s));
     HIP_OK(h, hipMemsetAsync(h->sep_cnt, 0, ((size_t)h->Tmax + 1) * 4, s));
+    const bool chain = text_chain_ok(h, B, 1);
     for (int t = 0; t < max_len; ++t) {
         // forward on the sequence so far, argmax of the last position, append (model.py:173-182)
-        rc = text_forward(h, ids_out + t, ld, B, 1, t, 1, nullptr, 0, ids_out + t + 1, ld, h->sep_cnt, t, s);
+        rc = text_forward(h, ids_out + t, ld, B, 1, t, 1, nullptr, 0, ids_out + t + 1, ld, h->sep_cnt, t, s,
+                          chain && t > 0, chain && t + 1 < max_len && t + 1 < h->c.max_text_pos);
         if (rc) return rc;
     }
     if (steps_out) HIP_OK(h, launch_finish_steps(h->sep_cnt, B, max_len, stop, steps_out, s));
@@ -1134,7 +1151,8 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
 
 // Speed-only switches at run time (the same ones the GITCAP_* environment variables set once per process): lets ONE process
 // check that results do not depend on them.  key 0: GEMM + LayerNorm epilogue on/off, 1: one/two-row prologue on/off,
-// 2: 256-tile threshold (GITCAP_GEMM_SMALL_TILES), 3: 128-tile threshold (GITCAP_GEMM_TINY_TILES), 4: 224-row tiles on/off.
+// 2: 256-tile threshold (GITCAP_GEMM_SMALL_TILES), 3: 128-tile threshold (GITCAP_GEMM_TINY_TILES), 4: 224-row tiles on/off,
+// 5: greedy loop chains token steps (the arg-max launch embeds the next step's input rows) on/off.
 // Returns the old value.
 int gitcap_dbg_config(int key, int value) {
     int old = -1;
@@ -1144,6 +1162,7 @@ int gitcap_dbg_config(int key, int value) {
         case 2: old = g_small_tiles.exchange(value); break;
         case 3: old = g_tiny_tiles.exchange(value); break;
         case 4: old = g_tile224.exchange(value != 0); break;
+        case 5: old = g_chain_steps.exchange(value != 0); break;
         default: return GITCAP_ERR_ARG;
     }
     return old;

@@ -82,9 +82,14 @@ hipError_t launch_skinny_splitk(const SkinnyArgs& a, hipStream_t s);
 hipError_t launch_ln_reduce(const float* slabs, int nslab, const float* bias, const float* resid,
                             const float* gamma, const float* beta, float eps, int M, int D,
                             float* xf, bf16_t* xb, hipStream_t s);
-// out[r*ld_out] = index of the max over the per-tile partials of row r*row_stride + row_off
+// out[r*ld_out] = index of the max over the per-tile partials of row r*row_stride + row_off.
+// emb (nullable; greedy loop, one position per row): the kernel goes on to embed the token it just chose at text position
+// emb->position -- word + position embedding -> LayerNorm -> xf / xb row r (rowln.h: the code of launch_embed_text) -- so
+// the next token step starts at its q|k|v projection.
+struct NextEmbed { const float *word, *pos, *gamma, *beta; float eps; int D, vocab, position; float* xf; bf16_t* xb; };
 hipError_t launch_argmax_final(const float* amax_val, const int* amax_idx, int ntiles, int rows, int row_stride,
-                               int row_off, int64_t* out, int ld_out, int32_t* sep_cnt, int step, int sep_id, hipStream_t s);
+                               int row_off, int64_t* out, int ld_out, int32_t* sep_cnt, int step, int sep_id, hipStream_t s,
+                               const NextEmbed* emb = nullptr);
 
 // ---- attention ---------------------------------------------------------------------------
 // Full (unmasked) self-attention over groups of S rows: qkv [G*S][3*W] bf16 (q | k | v, head h

@@ -69,17 +69,13 @@ __device__ __forceinline__ float row_load_reduce(f32x4 (&v)[NV], const float* __
     return s;
 }
 
-// v = word[ids[r*ld_ids + j]] + pos[t0 + j], m = r*T + j; returns the lane-sum
+// v = word[tok] + pos[position]; returns the lane-sum
 template <int NV>
-__device__ __forceinline__ float row_load_embed(f32x4 (&v)[NV], const int64_t* __restrict__ ids, const int ld_ids,
-                                                const int T, const int t0, const float* __restrict__ word,
-                                                const float* __restrict__ pos, const int D, const int vocab, const int m,
-                                                const int lane) {
-    const int r = m / T, j = m - r * T;
-    int64_t tok = ids[(size_t)r * ld_ids + j];
+__device__ __forceinline__ float row_load_embed_tok(f32x4 (&v)[NV], int64_t tok, const int position, const float* __restrict__ word,
+                                                    const float* __restrict__ pos, const int D, const int vocab, const int lane) {
     tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);          // never index outside the table
     const float* wr = word + (size_t)tok * D;
-    const float* pr = pos + (size_t)(t0 + j) * D;
+    const float* pr = pos + (size_t)position * D;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -90,6 +86,16 @@ __device__ __forceinline__ float row_load_embed(f32x4 (&v)[NV], const int64_t* _
         } else v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     return s;
+}
+
+// v = word[ids[r*ld_ids + j]] + pos[t0 + j], m = r*T + j; returns the lane-sum
+template <int NV>
+__device__ __forceinline__ float row_load_embed(f32x4 (&v)[NV], const int64_t* __restrict__ ids, const int ld_ids,
+                                                const int T, const int t0, const float* __restrict__ word,
+                                                const float* __restrict__ pos, const int D, const int vocab, const int m,
+                                                const int lane) {
+    const int r = m / T, j = m - r * T;
+    return row_load_embed_tok<NV>(v, ids[(size_t)r * ld_ids + j], t0 + j, word, pos, D, vocab, lane);
 }
 
 // fp32 and/or bf16 copies of the row (either pointer may be null)

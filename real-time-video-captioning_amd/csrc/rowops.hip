@@ -233,12 +233,14 @@ __global__ __launch_bounds__(64) void ln_reduce_kernel(const float* __restrict__
 }
 
 // ---- final arg-max over the per-tile partials written by the vocabulary-head kernel ------------
+template <int NV>
 __global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restrict__ val, const int* __restrict__ idx,
                                                            int ntiles, int row_stride, int row_off,
                                                            int64_t* __restrict__ out, int ld_out,
-                                                           int32_t* __restrict__ sep_cnt, int step, int sep_id) {
+                                                           int32_t* __restrict__ sep_cnt, int step, int sep_id, NextEmbed emb) {
     __shared__ float sv[4];
     __shared__ int si[4];
+    __shared__ int chosen;
     const int r = blockIdx.x, tid = threadIdx.x;
     const size_t base = (size_t)(r * row_stride + row_off) * ntiles;
     float best = -INFINITY;
@@ -262,6 +264,16 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restri
         if (bi == 0x7fffffff) bi = 0;
         out[(size_t)r * ld_out] = bi;
         if (sep_cnt && bi == sep_id) atomicAdd(&sep_cnt[step], 1);
+        chosen = bi;
+    }
+    if (NV > 0) {       // the next step's input row: embedding of the token just chosen + LayerNorm (one wave)
+        __syncthreads();
+        if (tid < 64) {
+            f32x4 v[NV > 0 ? NV : 1];
+            const float s = row_load_embed_tok<(NV > 0 ? NV : 1)>(v, (int64_t)chosen, emb.position, emb.word, emb.pos, emb.D, emb.vocab, tid);
+            row_layernorm<(NV > 0 ? NV : 1)>(v, s, tid, emb.D, emb.eps, emb.gamma, emb.beta);
+            row_store<(NV > 0 ? NV : 1)>(v, tid, emb.D, emb.xf + (size_t)r * emb.D, emb.xb + (size_t)r * emb.D);
+        }
     }
 }
 
@@ -570,9 +582,20 @@ hipError_t launch_ln_reduce(const float* slabs, int nslab, const float* bias, co
 }
 
 hipError_t launch_argmax_final(const float* amax_val, const int* amax_idx, int ntiles, int rows, int row_stride, int row_off,
-                               int64_t* out, int ld_out, int32_t* sep_cnt, int step, int sep_id, hipStream_t s) {
-    hipLaunchKernelGGL(argmax_final_kernel, dim3(rows), dim3(256), 0, s, amax_val, amax_idx, ntiles, row_stride, row_off,
-                       out, ld_out, sep_cnt, step, sep_id);
+                               int64_t* out, int ld_out, int32_t* sep_cnt, int step, int sep_id, hipStream_t s, const NextEmbed* emb) {
+    const NextEmbed e = emb ? *emb : NextEmbed{};
+    const int nv = emb ? (e.D + 255) / 256 : 0;
+    if (emb && (nv < 1 || nv > 4 || (e.D & 3) || !e.word || !e.pos || !e.gamma || !e.beta || !e.xf || !e.xb)) return hipErrorInvalidValue;
+#define AF_LAUNCH(NV) hipLaunchKernelGGL(argmax_final_kernel<NV>, dim3(rows), dim3(256), 0, s, amax_val, amax_idx, ntiles, row_stride, row_off, \
+                                         out, ld_out, sep_cnt, step, sep_id, e)
+    switch (nv) {
+        case 0: AF_LAUNCH(0); break;
+        case 1: AF_LAUNCH(1); break;
+        case 2: AF_LAUNCH(2); break;
+        case 3: AF_LAUNCH(3); break;
+        default: AF_LAUNCH(4); break;
+    }
+#undef AF_LAUNCH
     return hipGetLastError();
 }
 
