@@ -240,7 +240,7 @@ int ln(gitcap* h, hipStream_t s, const float* x, int ldx, const float* g, const 
 // tiles the 128x128 kernel (4x the workgroups, two per CU) is used (B=1: 7.7 -> 6.8 ms per caption), and below
 // g_tiny_tiles of THOSE the 64x64 kernel (16x, three per CU, 3-stage ring: the single-clip launches).  Big launches
 // take 256(n) x 224(m) tiles where that turns partial rounds on the 256 CUs into full ones (the bench shape: every GEMM,
-// -12.5 % K-loop time).  All tile kernels produce bitwise identical results (tests/test_kernels_gpu.py), so the choice
+// -3 ... -5 % per launch measured; synchronous calls only, see g_tile224).  All tile kernels produce bitwise identical results (tests/test_kernels_gpu.py), so the choice
 // only affects speed.
 // Weights: bf16, or e4m3 bytes + row scales (W.scale != nullptr).  The tile kernels read e4m3 panels through bf16
 // staging (a few MB: it stays in L2 / the Infinity Cache; HBM sees the e4m3 bytes): the four matrices of a transformer
