@@ -914,11 +914,13 @@ static int greedy_text_loop(gitcap* h, int B, int max_len, int stop, int64_t* id
     HIP_OK(h, launch_fill_i64(ids_out, ld, B, h->c.cls_token_id, s));
     HIP_OK(h, hipMemsetAsync(h->sep_cnt, 0, ((size_t)h->Tmax + 1) * 4, s));
     const bool chain = text_chain_ok(h, B, 1);
+    bool have_rows = false;                                  // the previous step's arg-max launch embedded this step's input rows
     for (int t = 0; t < max_len; ++t) {
         // forward on the sequence so far, argmax of the last position, append (model.py:173-182)
-        rc = text_forward(h, ids_out + t, ld, B, 1, t, 1, nullptr, 0, ids_out + t + 1, ld, h->sep_cnt, t, s,
-                          chain && t > 0, chain && t + 1 < max_len && t + 1 < h->c.max_text_pos);
+        const bool next = chain && t + 1 < max_len && t + 1 < h->c.max_text_pos;
+        rc = text_forward(h, ids_out + t, ld, B, 1, t, 1, nullptr, 0, ids_out + t + 1, ld, h->sep_cnt, t, s, have_rows, next);
         if (rc) return rc;
+        have_rows = next;
     }
     if (steps_out) HIP_OK(h, launch_finish_steps(h->sep_cnt, B, max_len, stop, steps_out, s));
     return 0;
