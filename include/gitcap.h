@@ -32,7 +32,8 @@ typedef enum {
     GITCAP_ERR_ARG = -1,      /* bad argument / shape outside what the handle was created for */
     GITCAP_ERR_STATE = -2,    /* call order violated (e.g. decode before prefill, weights missing) */
     GITCAP_ERR_HIP = -3,      /* a HIP runtime call failed */
-    GITCAP_ERR_NOMEM = -4
+    GITCAP_ERR_NOMEM = -4,
+    GITCAP_ERR_EXCHANGE = -5  /* a fused GEMM + LayerNorm launch gave up waiting for its sibling tiles (see gitcap_poll_errors) */
 } gitcap_status;
 
 typedef enum { GITCAP_F32 = 0, GITCAP_BF16 = 1 } gitcap_dtype;
@@ -185,6 +186,16 @@ int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max
                          int64_t* ids_out, int32_t* steps_out, void* stream, int* ticket);
 int gitcap_greedy_wait(gitcap_t* h, int ticket, void* stream);
 
+/* Health of the in-kernel statistics exchange (no reference counterpart).  The residual GEMMs that normalise their own output
+ * rows exchange LayerNorm statistics between the workgroups of a row block (co-residency).  If a workgroup ever
+ * gives up waiting (about 30 s: its siblings cannot become resident because another process or a CU-masked stream holds the
+ * CUs) the kernel does NOT trap: it raises a host-visible flag and finishes with undefined rows.  Every entry point above
+ * checks the flag first and gitcap_poll_errors checks it on demand (call it after synchronising the stream to vouch for the
+ * results just produced).  Once raised: the device is drained, the flag is cleared, the handle switches for good to the
+ * unfused GEMM + LayerNorm launches (bitwise the same results) and GITCAP_ERR_EXCHANGE is returned ONCE -- the caller
+ * re-runs the calls whose results it had not yet vouched for.  Returns 0 when healthy. */
+int gitcap_poll_errors(gitcap_t* h);
+
 /* Beam reorder of the text part of the KV cache (what src/models/model.py:623-634 sketches):
  * new row r takes the cached text K/V of old row src_rows[r]; image K/V are shared. */
 int gitcap_reorder_rows(gitcap_t* h, const int32_t* src_rows, int rows, int t_len, void* stream);
@@ -223,7 +234,8 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
 /* Speed-only switches at run time (what the GITCAP_* environment variables set once per process; INTEGRATION.md par. 9), so that
  * one process can check that results do not depend on them.  key 0: GEMM + LayerNorm epilogue on/off; 1: one/two-row prologue
  * on/off; 2: 256x256-tile threshold; 3: 128x128-tile threshold; 4: 224-row tiles for synchronous calls on/off; 5: the greedy loop's
- * arg-max launch also embeds the next step's input rows on/off.  Returns the previous value (< 0: bad key).  The switches are process-wide atomics: a call on another thread sees either value,
+ * arg-max launch also embeds the next step's input rows on/off; 6: polls a fused GEMM + LayerNorm workgroup waits for its
+ * siblings before it gives up (0 = default; 1 forces the fail-soft path of gitcap_poll_errors in a test).  Returns the previous value (< 0: bad key).  The switches are process-wide atomics: a call on another thread sees either value,
  * and either value gives the same bits. */
 int gitcap_dbg_config(int key, int value);
 /* attn_full: qkv [G*S][3*H*64] bf16 -> ctx [G*S][H*64] bf16 */

@@ -41,11 +41,25 @@ def _r(x: torch.Tensor, on: bool) -> torch.Tensor:
     return x.to(torch.bfloat16).to(torch.float32) if on else x
 
 
+def _q8(x: torch.Tensor) -> torch.Tensor:
+    """OCP e4m3 with one power-of-two scale per row (the smallest 2^e with amax / 2^e <= 448; e4m3 x 2^e is a bf16
+    value): the activation encoding of the opt-in fp8-MFMA image pass (csrc: act_quant; DESIGN.md par. 3).  Rounds to
+    nearest even, saturates at +-448 x scale (cannot happen: the scale covers the row's amax)."""
+    amax = x.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
+    e = torch.ceil(torch.log2(amax / 448.0))
+    s = torch.exp2(e)
+    s = torch.where(s * 448.0 < amax, s * 2.0, s)               # log2 rounding at exact powers of two
+    return (x / s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) * s
+
+
 class GitOracle:
     def __init__(self, cfg, weights: Dict[str, np.ndarray], emulate_bf16: bool = False,
-                 threads: Optional[int] = None):
+                 threads: Optional[int] = None, emulate_fp8_act: bool = False):
         self.cfg = cfg
         self.bf = bool(emulate_bf16)
+        # opt-in fp8 MFMA compute of the IMAGE pass: the activation operand of every image-row GEMM (not the patch
+        # embedding, not the text rows) is e4m3 with a per-row power-of-two scale instead of bf16
+        self.f8 = bool(emulate_fp8_act)
         if threads:
             torch.set_num_threads(threads)
         self.w: Dict[str, torch.Tensor] = {}
@@ -57,9 +71,10 @@ class GitOracle:
             self.w[k] = t
 
     # ------------------------------------------------------------------ primitives
-    def _lin(self, x, name):
-        """y = bf16(x) @ bf16(W)^T + b with fp32 accumulation."""
-        return Fn.linear(_r(x, self.bf), self.w[name + ".w"], self.w[name + ".b"])
+    def _lin(self, x, name, img: bool = False):
+        """y = bf16(x) @ bf16(W)^T + b with fp32 accumulation (img: an image-row GEMM, e4m3 activations when emulate_fp8_act)."""
+        xin = _q8(_r(x, self.bf)) if (img and self.f8) else _r(x, self.bf)
+        return Fn.linear(xin, self.w[name + ".w"], self.w[name + ".b"])
 
     def _ln(self, x, name, eps):
         return Fn.layer_norm(x, (x.shape[-1],), self.w[name + ".w"], self.w[name + ".b"], eps)
@@ -105,14 +120,14 @@ class GitOracle:
         for i in range(cfg.enc_layers):
             pre = f"enc.L{i}."
             h = self._ln(x, pre + "ln1", cfg.enc_ln_eps)
-            qkv = _r(self._lin(h, pre + "qkv"), self.bf)
+            qkv = _r(self._lin(h, pre + "qkv", True), self.bf)
             q, k, v = (self._heads(t, H) for t in qkv.split(Dv, dim=-1))
             a = self._merge(self._attn(q, k, v, full))
-            x = x + self._lin(a, pre + "proj")
+            x = x + self._lin(a, pre + "proj", True)
             h = self._ln(x, pre + "ln2", cfg.enc_ln_eps)
-            h = self._lin(h, pre + "fc1")
+            h = self._lin(h, pre + "fc1", True)
             h = h * torch.sigmoid(1.702 * h)                                       # QuickGELU
-            x = x + self._lin(h, pre + "fc2")
+            x = x + self._lin(h, pre + "fc2", True)
         x = self._ln(x, "enc.ln_post", cfg.enc_ln_eps)
         x = x.view(B, F, N, Dv)
         if cfg.num_frames:
@@ -121,7 +136,7 @@ class GitOracle:
 
     # ------------------------------------------------------------------ projection (a4)
     def project(self, visual: torch.Tensor) -> torch.Tensor:
-        return self._ln(self._lin(visual, "vproj"), "vproj.ln", self.cfg.proj_ln_eps)
+        return self._ln(self._lin(visual, "vproj", True), "vproj.ln", self.cfg.proj_ln_eps)
 
     # ------------------------------------------------------------------ text embedding (a5)
     def embed_text(self, ids: torch.Tensor, pos0: int = 0) -> torch.Tensor:
@@ -130,22 +145,22 @@ class GitOracle:
         return self._ln(e, "txt.ln", self.cfg.dec_ln_eps)
 
     # ------------------------------------------------------------------ decoder (a6,a7)
-    def _dec_layer(self, i, x, k_all, v_all, klimit):
-        """x [B,Tq,D] query rows; k_all/v_all [B,H,Tk,64] all visible keys (incl. this block)."""
+    def _dec_layer(self, i, x, k_all, v_all, klimit, img: bool = False):
+        """x [B,Tq,D] query rows; k_all/v_all [B,H,Tk,64] all visible keys (incl. this block).  img: image rows only."""
         cfg = self.cfg
         pre = f"dec.L{i}."
         D, H = cfg.dec_width, cfg.dec_heads
-        qkv = _r(self._lin(x, pre + "qkv"), self.bf)
+        qkv = _r(self._lin(x, pre + "qkv", img), self.bf)
         q = self._heads(qkv[..., :D], H)
         a = self._merge(self._attn(q, k_all, v_all, klimit))
-        h = self._ln(self._lin(a, pre + "ao") + x, pre + "ln1", cfg.dec_ln_eps)
-        f = Fn.gelu(self._lin(h, pre + "fc1"))                                     # erf GELU
-        return self._ln(self._lin(f, pre + "fc2") + h, pre + "ln2", cfg.dec_ln_eps)
+        h = self._ln(self._lin(a, pre + "ao", img) + x, pre + "ln1", cfg.dec_ln_eps)
+        f = Fn.gelu(self._lin(h, pre + "fc1", img))                                # erf GELU
+        return self._ln(self._lin(f, pre + "fc2", img) + h, pre + "ln2", cfg.dec_ln_eps)
 
-    def _kv(self, i, x):
+    def _kv(self, i, x, img: bool = False):
         cfg = self.cfg
         D, H = cfg.dec_width, cfg.dec_heads
-        qkv = _r(self._lin(x, f"dec.L{i}.qkv"), self.bf)
+        qkv = _r(self._lin(x, f"dec.L{i}.qkv", img), self.bf)
         return self._heads(qkv[..., D:2 * D], H), self._heads(qkv[..., 2 * D:], H)
 
     def decoder_full(self, memory: torch.Tensor, ids: torch.Tensor,
@@ -176,10 +191,10 @@ class GitOracle:
         x, kv = memory, []
         full = torch.full((S_img,), S_img)
         for i in range(cfg.dec_layers):
-            k, v = self._kv(i, x)
+            k, v = self._kv(i, x, True)
             kv.append((k, v))
             if i + 1 < cfg.dec_layers:
-                x = self._dec_layer(i, x, k, v, full)
+                x = self._dec_layer(i, x, k, v, full, True)
         return kv
 
     def decoder_text(self, image_kv, ids: torch.Tensor, clip_of_row: torch.Tensor | None = None) -> torch.Tensor:

@@ -188,17 +188,17 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const bf16_t* __restrict
         mt = fmaxf(mt, __shfl_xor(mt, 32));
         const float m_new = fmaxf(m_run, mt);
         const float alpha = fast_exp2((m_run - m_new) * kScaleLog2e);
-        const float mb = m_new * kScaleLog2e;
+        const float mb = -(m_new * kScaleLog2e);
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = fast_exp2(s_acc[kt][r] * kScaleLog2e - mb);
+                const float p = fast_exp2(__builtin_fmaf(s_acc[kt][r], kScaleLog2e, mb));     // spelled out: -ffp-contract=off
                 s_acc[kt][r] = p;
                 psum += p;
             }
-        l_run = l_run * alpha + psum;
+        l_run = __builtin_fmaf(l_run, alpha, psum);
         // O only needs rescaling when some query's running max moved (rare after the first tiles);
         // the branch is wave-uniform and exact (alpha == 1 for every lane otherwise)
         if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {

@@ -63,6 +63,10 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// The library is compiled with -ffp-contract=off: the compiler never fuses a multiply with an add on its own, so the
+// rounding of every fp32 expression is what the source says, in every kernel and every instantiation (three tile kernels
+// share these epilogue functions and must agree bit for bit; batch invariance rests on it).  Where a fused multiply-add is
+// wanted it is written as __builtin_fmaf.
 // x * sigmoid(1.702 x) with v_exp_f32 / v_rcp_f32 (each ~1 ulp; the result is rounded to bf16)
 __device__ __forceinline__ float quick_gelu(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * x));
@@ -71,14 +75,17 @@ __device__ __forceinline__ float quick_gelu(float x) {
 // erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1/(1 + p z), z >= 0; odd extension.
 __device__ __forceinline__ float fast_erf(float x) {
     const float z = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
     float p = 1.061405429f;
-    p = p * t - 1.453152027f;
-    p = p * t + 1.421413741f;
-    p = p * t - 0.284496736f;
-    p = p * t + 0.254829592f;
+    p = __builtin_fmaf(p, t, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
     const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
-    const float r = 1.0f - p * t * e;
+    const float r = __builtin_fmaf(-(p * t), e, 1.0f);
     return copysignf(r, x);
 }
-__device__ __forceinline__ float erf_gelu(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float erf_gelu(float x) {
+    const float hx = 0.5f * x;
+    return __builtin_fmaf(hx, fast_erf(x * 0.70710678118654752f), hx);
+}

@@ -290,7 +290,7 @@ hipError_t launch_t(const GemmArgs& a0, hipStream_t s) {
     GemmArgs a = a0;
     int grid = (a.M >> 8) * (a.N >> 8);
     if (LN) {                                       // whole row blocks per XCD wherever the grid runs in rounds (host_logic.h)
-        a.ln_rowblock_map = ln_use_rowblock_map(a.M >> 8, a.N >> 8) ? 1 : 0;
+        a.ln_rowblock_map = ln_use_rowblock_map(a.M >> 8, a.N >> 8, device_cus()) ? 1 : 0;
         if (a.ln_rowblock_map) grid = ln_grid_size(a.M >> 8, a.N >> 8);
     }
     hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS, s, a);

@@ -113,7 +113,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // publishes, so the wait is bounded by the slowest sibling; an XCD dispatches its workgroups in index order, so a
 // waiting tile can only wait for a tile that is resident on the same XCD or that is dispatched as soon as any tile of
 // that XCD with all siblings resident retires: no deadlock as long as an XCD can hold N/256 workgroups of this kernel
-// at once ("co-residency"); the spin is bounded + trap.  Ordering: every wave drains its write-through
+// at once ("co-residency"); the spin is bounded and fails soft (a host-visible flag, no trap).  Ordering: every wave drains its write-through
 // (sc1) statistics stores with s_waitcnt vmcnt(0) before the workgroup barrier that precedes the arrival, the arrival and
 // the poll are agent-scope atomics, and the statistics are fetched with sc1 loads issued after the poll succeeded (the
 // "write-through store; drain; flag" form of MI355X_MICROARCH.md; agent-scope fences measured 5.4 vs 1.9 us per exchange).
@@ -188,9 +188,13 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
     LN_STAMP(4);
     if (threadIdx.x == 0 && !last) {
         unsigned spins = 0;
+        const unsigned limit = a.ln_spin_limit ? a.ln_spin_limit : LN_SPIN_DEFAULT;
         while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen) {
             __builtin_amdgcn_s_sleep(12);                   // ~0.3 us between polls: 200 spinning tiles must not load the fabric
-            if (++spins > (1u << 26)) __builtin_trap();     // ~30 s: far beyond any preemption of a sibling; a lost arrival is loud
+            if (++spins > limit) {                          // ~30 s: far beyond any preemption of a sibling.  No trap: tell the
+                if (a.ln_fail) __hip_atomic_store(a.ln_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host and finish
+                break;                                      // (the rows of this block are undefined; host_logic.h: ExchangeHealth)
+            }
         }
     }
     __syncthreads();

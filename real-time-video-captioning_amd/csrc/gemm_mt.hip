@@ -195,9 +195,13 @@ __device__ __forceinline__ void epilogue_tile_ln(const GemmArgs& a, const f32x4 
     }
     if (threadIdx.x == 0 && !last) {
         unsigned spins = 0;
+        const unsigned limit = a.ln_spin_limit ? a.ln_spin_limit : LN_SPIN_DEFAULT;
         while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen) {
             __builtin_amdgcn_s_sleep(12);
-            if (++spins > (1u << 26)) __builtin_trap();     // ~30 s: a lost arrival is loud
+            if (++spins > limit) {                          // ~30 s: fail soft (gemm_epilogue.h; host_logic.h: ExchangeHealth)
+                if (a.ln_fail) __hip_atomic_store(a.ln_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
         }
     }
     __syncthreads();
@@ -468,7 +472,7 @@ hipError_t launch_t(const GemmArgs& a0, hipStream_t s) {
     const int nrb = a.M / (32 * MT), ntn = a.N >> 8;
     int grid = nrb * ntn;
     if (LN) {
-        a.ln_rowblock_map = ln_use_rowblock_map(nrb, ntn) ? 1 : 0;
+        a.ln_rowblock_map = ln_use_rowblock_map(nrb, ntn, device_cus()) ? 1 : 0;
         if (a.ln_rowblock_map) grid = ln_grid_size(nrb, ntn);
     }
     hipLaunchKernelGGL((gemm_mt_kernel<EPI, MT>), dim3(grid), dim3(512), LDS, s, a);

@@ -26,6 +26,21 @@
 // g_row_prologue is shared with student.hip.
 std::atomic<bool> g_row_prologue{!env_flag("GITCAP_NO_ROW_PROLOGUE")};
 
+// compute units of the current device, cached per device (the workgroup -> tile maps and the tile-height choice depend on it)
+int device_cus() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::atomic<int>& c = cache[dev & 63];
+    int v = c.load(std::memory_order_relaxed);
+    if (v <= 0) {
+        int n = 0;
+        v = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+        c.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 namespace {
 
 // a GEMM weight [Npad16][K]: bf16, or OCP e4m3 bytes + one power-of-two scale per row (scale != nullptr)
@@ -76,6 +91,10 @@ struct gitcap {
     float *x = nullptr, *tmp = nullptr;
     float2* ln_stats = nullptr;         // [Mi][16] LayerNorm segment statistics exchanged inside the fused GEMMs
     unsigned* ln_cnt = nullptr;         // [Mi / 256][2] {arrivals, generation} per 256-row block (self-resetting barrier)
+    size_t ln_cnt_words = 0;
+    unsigned* ln_fail = nullptr;        // host-pinned word a fused launch raises when a tile gave up waiting (gemm_epilogue.h)
+    ExchangeHealth xh;                  // host_logic.h: once raised, the handle runs GEMM + row kernel for good
+    int cus = 256;                      // compute units of the handle's device
     bf16_t *hb = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr, *patches = nullptr, *kv_img = nullptr;
     // workspace (text rows)
     float *xs = nullptr, *xs2 = nullptr, *slabs = nullptr, *part = nullptr, *amax_val = nullptr;
@@ -123,7 +142,6 @@ struct gitcap {
     hipStream_t s_enc = nullptr;
     hipStream_t txt_streams[NSLOT] = {nullptr, nullptr, nullptr, nullptr};   // owned; slot i decodes on txt_streams[i % n_txt]
     int n_txt = NSLOT;
-    double prof_rows = 0;   // valid rows of the GEMMs being launched (set by the callers of gemm())
     bool pipelined = false; // the launches being issued belong to a gitcap_greedy_submit (other batches share the chip)
 
     // instrumentation (bench.py): HIP-event brackets per kernel class, on the launch stream
@@ -155,6 +173,9 @@ std::atomic<int> g_tiny_tiles{getenv("GITCAP_GEMM_TINY_TILES") ? atoi(getenv("GI
 // (1670 vs 1742 captions/s, same box).  So submissions (gitcap_greedy_submit) keep 256-row tiles unless
 // GITCAP_TILE224_PIPELINED is set (1: every big launch, 2: only launches of several rounds; experiment switch).
 std::atomic<bool> g_tile224{!env_flag("GITCAP_NO_TILE224")};
+// polls a tile of a fused GEMM + LayerNorm launch spends waiting for its siblings before it gives up (0 = LN_SPIN_DEFAULT,
+// ~30 s).  gitcap_dbg_config(6, n): a test forces the give-up path with n = 1.
+std::atomic<unsigned> g_ln_spin_limit{0};
 const int g_tile224_pipe = getenv("GITCAP_TILE224_PIPELINED") ? atoi(getenv("GITCAP_TILE224_PIPELINED")) : 0;
 
 int fail(const gitcap* h, int code, const std::string& msg) {
@@ -186,6 +207,21 @@ hipError_t join_async(gitcap* h, hipStream_t stream) {
         }
     return hipSuccess;
 }
+
+// The statistics exchange of the fused GEMM + LayerNorm launches fails soft (gemm_epilogue.h): a tile that gave up waiting
+// raised h->ln_fail.  Checked at every entry point that issues or joins device work and by gitcap_poll_errors: the device is
+// drained, the word and the exchange barriers are reset, the handle stops using the fused epilogues (the GEMM + row-kernel
+// form gives the same bits) and the caller is told once, so that it re-runs what it had in flight.
+int poll_exchange(gitcap* h) {
+    if (!h->ln_fail || !exchange_poll(h->xh, *(volatile unsigned*)h->ln_fail)) return 0;
+    (void)hipDeviceSynchronize();
+    *(volatile unsigned*)h->ln_fail = 0;
+    if (h->ln_cnt) (void)hipMemset(h->ln_cnt, 0, h->ln_cnt_words * sizeof(unsigned));
+    return fail(h, GITCAP_ERR_EXCHANGE, "a GEMM + LayerNorm launch timed out waiting for its sibling tiles (CUs held by another "
+                "process or a CU-masked stream?): results since the last call are undefined -- re-run them; this handle now uses "
+                "separate LayerNorm launches");
+}
+#define POLL(h) do { int rc_ = poll_exchange(h); if (rc_) return rc_; } while (0)
 
 #define HIP_OK(h, expr)                                                                               \
     do {                                                                                              \
@@ -250,24 +286,31 @@ int ln(gitcap* h, hipStream_t s, const float* x, int ldx, const float* g, const 
 // slower per launch, 32 v_cvt_scalef32_pk_bf16_fp8 per wave and K-tile next to 56-64 MFMAs
 // (profiles/r03_gemm_e4m3_direct_vs_bf16.txt); expanding panel i+1 on a side stream while GEMM i runs (two-slot ring,
 // events both ways): image pass 11.0 vs 10.3 ms, a cross-stream event hand-off costs more than the 3 us it hides.
-hipError_t launch_gemm_auto(gitcap* h, GemmArgs a, const WRef& W, int epi, hipStream_t s, int rows) {
+// e4m3 storage: the bf16 panel a tile kernel reads for W -- the layer staging area when stage_layer expanded it, else the
+// single-panel staging filled by a launch of its own, issued HERE (in front of the caller's ProfScope: a staging launch is
+// not GEMM time).  bf16 storage: W itself.
+hipError_t resolve_weight(gitcap* h, const WRef& W, int N, int K, hipStream_t s, const bf16_t** out) {
+    *out = (const bf16_t*)W.p;
+    if (!W.scale) return hipSuccess;
+    for (int i = 0; i < h->n_staged; ++i)
+        if (h->staged_src[i] == W.p) { *out = h->staged_dst[i]; return hipSuccess; }       // expanded at the head of the layer
+    ProfScope ps(h, GITCAP_PROF_ROWOPS, s, 0.0, 3.0 * pad_to(N, 16) * (double)K);
+    const hipError_t e = launch_dequant_fp8((const unsigned char*)W.p, W.scale, h->wstage, pad_to(N, 16), K, s);
+    *out = h->wstage;
+    return e;
+}
+
+// `rows` = the valid rows of the launch (a.M = rows padded to 256); `cap` = rows of the A / output buffers (h->Mi, or h->Pp
+// for the patch GEMM): a launch on 224-row tiles covers ceil224(rows) rows and its LDS-DMA pieces read 16 further.
+hipError_t launch_gemm_auto(gitcap* h, GemmArgs a, int epi, hipStream_t s, int rows, int cap) {
     const bool ln = epi == EPI_RESID_LN_PRE || epi == EPI_RESID_LN_POST;
-    a.W = (const bf16_t*)W.p;
-    if (W.scale) {
-        const bf16_t* st = nullptr;
-        for (int i = 0; i < h->n_staged; ++i)
-            if (h->staged_src[i] == W.p) st = h->staged_dst[i];                // expanded at the head of the layer
-        if (!st) {
-            const hipError_t e = launch_dequant_fp8((const unsigned char*)W.p, W.scale, h->wstage, pad_to(a.N, 16), a.K, s);
-            if (e != hipSuccess) return e;
-            st = h->wstage;
-        }
-        a.W = st;
-    }
+    if (ln) { a.ln_fail = h->ln_fail; a.ln_spin_limit = g_ln_spin_limit; }
     if (gemm256_ok(a) && (a.M >> 8) * (a.N >> 8) >= g_small_tiles) {
-        const bool allow224 = g_tile224 && (!h->pipelined || g_tile224_pipe == 1 || (g_tile224_pipe == 2 && (a.M >> 8) * (a.N >> 8) > 256));
-        const bool t224 = allow224 && rows > 0 && pick_tile_rows(rows, a.N, ln) == 224;
-        if (t224) a.M = (rows + 223) / 224 * 224;                 // the workspace holds 256 rows beyond the 256-padded rows
+        const bool allow224 = g_tile224 && (!h->pipelined || g_tile224_pipe == 1 || (g_tile224_pipe == 2 && (a.M >> 8) * (a.N >> 8) > h->cus));
+        const int m224 = (rows + 223) / 224 * 224;
+        const bool t224 = allow224 && rows > 0 && pad_to(rows, 256) == a.M && m224 + 16 <= cap &&
+                          pick_tile_rows(rows, a.N, ln, h->cus) == 224;
+        if (t224) a.M = m224;
         return t224 ? launch_gemm_mt(a, epi, 224, s) : launch_gemm256(a, epi, s);
     }
     if (ln) return hipErrorInvalidValue;
@@ -298,16 +341,18 @@ int stage_layer(gitcap* h, hipStream_t s, const WRef* const* Ws, const int* rows
     return 0;
 }
 
-int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef& W, const float* bias, int M, int N,
+// `rows` = the valid rows (M = rows padded to 256): the algorithmic work of the bracket and what the tile choice is made on
+int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef& W, const float* bias, int rows, int M, int N,
          int K, void* out, int ldo, const float* resid = nullptr, int ldr = 0) {
-    // algorithmic work: the VALID rows (h->prof_rows), not the 128-padded M that is launched; bytes = operands once +
-    // the output (+ the fp32 residual read)
-    const double R = h->prof_rows, osz = (epi == EPI_BIAS_RESID_F32 || epi == EPI_BIAS_F32 || epi == EPI_PATCH_F32) ? 4.0 : 2.0;
-    ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * R * N * K, 2.0 * R * K + 2.0 * N * K + R * N * (osz + (resid ? 4.0 : 0.0)));
     GemmArgs a{};
+    HIP_OK(h, resolve_weight(h, W, N, K, s, &a.W));
+    // algorithmic work: the VALID rows, not the padded M that is launched; bytes = operands once + the output (+ the fp32
+    // residual read)
+    const double R = rows, osz = (epi == EPI_BIAS_RESID_F32 || epi == EPI_BIAS_F32 || epi == EPI_PATCH_F32) ? 4.0 : 2.0;
+    ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * R * N * K, 2.0 * R * K + 2.0 * N * K + R * N * (osz + (resid ? 4.0 : 0.0)));
     a.A = A; a.lda = lda; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = ldo;
     a.resid = resid; a.ldr = ldr;
-    HIP_OK(h, launch_gemm_auto(h, a, W, epi, s, (int)h->prof_rows));
+    HIP_OK(h, launch_gemm_auto(h, a, epi, s, rows, h->Mi));
     return 0;
 }
 
@@ -316,7 +361,8 @@ int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef
 //   post = true  (post-LN decoder):    x = A W^T + bias [+ resid] -> scratch; xout = fp32 LN(x) (may alias resid); ln_b = bf16 LN(x)
 // Large launches run both inside the 256x256 kernel (EPI_RESID_LN_*: the tiles of a row block exchange segment
 // statistics); small ones the 128x128 kernel + the row kernel.  Both give the same bits (ln_canon.h).
-// GITCAP_NO_GEMM_LN=1 (diagnosis / A-B only) keeps every LayerNorm a launch of its own.
+// GITCAP_NO_GEMM_LN=1 (diagnosis / A-B only) keeps every LayerNorm a launch of its own; so does a handle whose exchange
+// ever timed out (poll_exchange).
 std::atomic<bool> g_fuse_ln{!env_flag("GITCAP_NO_GEMM_LN")};
 
 int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const WRef& W, const float* bias, int M, int N,
@@ -330,16 +376,18 @@ int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const
     // ln_out may be the A operand itself (visual projection): a tile writes its rows only after every tile that reads
     // them has finished its K loop (that is what the exchange waits for) -- as long as both views have the same row stride
     const bool alias_ok = (const void*)A != (const void*)ln_out || lda == N;
-    if (g_fuse_ln && alias_ok && gemm256_ln_ok(a) && (M >> 8) * (N >> 8) >= g_small_tiles && (post ? (xout && !addv && !ln_f32) : resid != nullptr)) {
-        const double R = h->prof_rows;      // A + W + fp32 out + bf16 LayerNorm out (+ fp32 residual read)
+    if (g_fuse_ln && !h->xh.degraded && alias_ok && gemm256_ln_ok(a) && (M >> 8) * (N >> 8) >= g_small_tiles &&
+        (post ? (xout && !addv && !ln_f32) : resid != nullptr)) {
+        HIP_OK(h, resolve_weight(h, W, N, K, s, &a.W));
+        const double R = rows;              // A + W + fp32 out + bf16 LayerNorm out (+ fp32 residual read)
         ProfScope ps(h, GITCAP_PROF_GEMM_LN, s, 2.0 * R * N * K, 2.0 * R * K + 2.0 * N * K + R * N * ((xout ? 4.0 : 0.0) + 2.0 + (ln_f32 ? 4.0 : 0.0) + (resid ? 4.0 : 0.0)));
-        HIP_OK(h, launch_gemm_auto(h, a, W, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s, rows));
+        HIP_OK(h, launch_gemm_auto(h, a, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s, rows, h->Mi));
         return 0;
     }
     int rc;
     // GEMM, then the row kernel: x goes to the scratch (post), to xout, or -- when the caller does not want it -- over the residual
     float* xo = post ? scratch : (xout ? xout : const_cast<float*>(resid));
-    if ((rc = gemm(h, s, resid ? EPI_BIAS_RESID_F32 : EPI_BIAS_F32, A, lda, W, bias, M, N, K, xo, N, resid, N))) return rc;
+    if ((rc = gemm(h, s, resid ? EPI_BIAS_RESID_F32 : EPI_BIAS_F32, A, lda, W, bias, rows, M, N, K, xo, N, resid, N))) return rc;
     return ln(h, s, xo, N, ln_g, ln_b, eps, rows, N, post ? xout : ln_f32, N, ln_out, N, addv, add_div, add_mod);
 }
 
@@ -370,7 +418,6 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
     const gitcap_config& c = h->c;
     const int D = h->D, Dv = h->Dv, rows = B * S, Mp = pad_to(rows, 256);
     int rc;
-    h->prof_rows = rows;
     h->n_staged = 0;
     // 'linearLn' projection: Linear(Dv -> D) + LayerNorm
     if ((rc = gemm_ln(h, s, true, h->hb, Dv, h->vproj_w, h->vproj_b, Mp, D, Dv, h->x, nullptr, h->vproj_lnw, h->vproj_lnb,
@@ -390,20 +437,20 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
                 const int wr[4] = {3 * D, D, c.dec_ffn, D}, wk[4] = {D, D, D, c.dec_ffn};
                 if ((rc = stage_layer(h, s, ws, wr, wk, 4))) return rc;
             }
-            if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, D, L.qkvw, L.qkvb, Mp, 3 * D, D, kv, 3 * D))) return rc;
+            if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, D, L.qkvw, L.qkvb, rows, Mp, 3 * D, D, kv, 3 * D))) return rc;
             {
                 ProfScope ps(h, GITCAP_PROF_ATTN_FULL, s, 4.0 * B * c.dec_heads * (double)S * S * 64, 0.0);
                 HIP_OK(h, launch_attn_full(kv, h->ctx, B, S, c.dec_heads, s));
             }
             if ((rc = gemm_ln(h, s, true, h->ctx, D, L.aow, L.aob, Mp, D, D, h->x, h->x, L.ln1w, L.ln1b, c.dec_ln_eps, rows,
                               h->hb, h->tmp))) return rc;
-            if ((rc = gemm(h, s, EPI_BIAS_GELU_BF16, h->hb, D, L.fc1w, L.fc1b, Mp, c.dec_ffn, D, h->ffn, c.dec_ffn))) return rc;
+            if ((rc = gemm(h, s, EPI_BIAS_GELU_BF16, h->hb, D, L.fc1w, L.fc1b, rows, Mp, c.dec_ffn, D, h->ffn, c.dec_ffn))) return rc;
             if ((rc = gemm_ln(h, s, true, h->ffn, c.dec_ffn, L.fc2w, L.fc2b, Mp, D, c.dec_ffn, h->x, h->x, L.ln2w, L.ln2b,
                               c.dec_ln_eps, rows, h->hb, h->tmp))) return rc;
             HIP_OK(h, keep(l + 1));
         } else {
             // last layer: image rows are only ever read as keys/values -> K,V projections only
-            if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, D, L.qkvw.rows_from(D, D), L.qkvb + D, Mp, 2 * D, D, kv + D, 3 * D))) return rc;
+            if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, D, L.qkvw.rows_from(D, D), L.qkvb + D, rows, Mp, 2 * D, D, kv + D, 3 * D))) return rc;
         }
     }
     h->cur_B = B; h->cur_S = S; h->have_image = true;
@@ -583,7 +630,13 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     rc = rc ? rc : ws_alloc(h, &h->x, Mi * Dm);
     rc = rc ? rc : ws_alloc(h, &h->tmp, Mi * h->D);
     rc = rc ? rc : ws_alloc(h, &h->ln_stats, Mi * 16);
-    rc = rc ? rc : ws_alloc(h, &h->ln_cnt, 2 * (Mi / 224 + 2));
+    h->ln_cnt_words = 2 * (Mi / 224 + 2);
+    rc = rc ? rc : ws_alloc(h, &h->ln_cnt, h->ln_cnt_words);
+    if (!rc) {
+        if (hipHostMalloc((void**)&h->ln_fail, 64, hipHostMallocMapped) != hipSuccess) rc = fail(h, GITCAP_ERR_NOMEM, "create: hipHostMalloc (exchange flag)");
+        else memset(h->ln_fail, 0, 64);
+    }
+    h->cus = device_cus();
     rc = rc ? rc : ws_alloc(h, &h->hb, Mi * Dm);
     rc = rc ? rc : ws_alloc(h, &h->qkv, Mi * 3 * h->Dv);
     rc = rc ? rc : ws_alloc(h, &h->ctx, Mi * Dm);
@@ -672,6 +725,7 @@ void gitcap_destroy(gitcap_t* h) {
         if (t) (void)hipStreamDestroy(t);
     if (h->s_enc) (void)hipStreamDestroy(h->s_enc);
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->ln_fail) (void)hipHostFree(h->ln_fail);
     for (auto& kv : h->w)
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto& kv : h->wscale)
@@ -730,6 +784,7 @@ int gitcap_load_tensor(gitcap_t* h, const char* name, const float* data, const i
     }
     t.loaded = true;
     h->finalized = false;
+    h->n_staged = 0;
     return 0;
 }
 
@@ -789,6 +844,7 @@ int gitcap_finalize_weights(gitcap_t* h) {
         L.ln1w = F(p + "ln1.w"); L.ln1b = F(p + "ln1.b"); L.fc1w = Wt(p + "fc1.w"); L.fc1b = F(p + "fc1.b");
         L.fc2w = Wt(p + "fc2.w"); L.fc2b = F(p + "fc2.b"); L.ln2w = F(p + "ln2.w"); L.ln2b = F(p + "ln2.b");
     }
+    h->n_staged = 0;
     HIP_OK(h, hipDeviceSynchronize());
     h->finalized = true;
     return 0;
@@ -797,6 +853,7 @@ int gitcap_finalize_weights(gitcap_t* h) {
 int gitcap_encode(gitcap_t* h, const float* frames, int B, int F, float* visual_out, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "encode: null handle");
     GUARD(h);
+    POLL(h);
     select_slot(h, 0);
     HIP_OK(h, join_async(h, (hipStream_t)stream));
     return encode_impl(h, FrameSrc{frames, nullptr, 0, 0}, B, F, visual_out, (hipStream_t)stream);
@@ -810,6 +867,7 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
     const int Dv = h->Dv, N = h->N, nf = B * F, rows = nf * N, Mp = pad_to(rows, 256);
     const int P = nf * h->G * h->G, Pp = pad_to(P, 256);
     h->have_image = false;
+    h->n_staged = 0;             // nothing staged yet in this pass (a stale entry could match a recycled address)
 
     // patchify (conv k = stride = p, no bias) + CLS + position embedding, then ln_pre
     if (src.u8) {     // raw camera frames: resize + crop + BGR->RGB + normalise fused with the patch gather (no fp32 frames)
@@ -820,13 +878,13 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
         HIP_OK(h, launch_im2col(src.f32, h->patches, nf, c.image_size, c.patch_size, h->Kp, s));
     }
     {
-        ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * P * Dv * (3.0 * c.patch_size * c.patch_size), 2.0 * P * h->Kp + 2.0 * Dv * h->Kp + 4.0 * P * Dv);
         GemmArgs a{};
+        HIP_OK(h, resolve_weight(h, h->patch_w, Dv, h->Kp, s, &a.W));
+        ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * P * Dv * (3.0 * c.patch_size * c.patch_size), 2.0 * P * h->Kp + 2.0 * Dv * h->Kp + 4.0 * P * Dv);
         a.A = h->patches; a.lda = h->Kp; a.bias = nullptr; a.M = Pp; a.N = Dv; a.K = h->Kp;
         a.out = h->x; a.ldo = Dv; a.pos = h->pos; a.tokens_per_frame = N; a.patches_per_frame = h->G * h->G; a.valid_rows = P;
-        HIP_OK(h, launch_gemm_auto(h, a, h->patch_w, EPI_PATCH_F32, s, P));
+        HIP_OK(h, launch_gemm_auto(h, a, EPI_PATCH_F32, s, P, h->Pp));
     }
-    h->prof_rows = rows;
     // ln_pre (fp32, in place: the residual stream) and the first block's LN1 (bf16: the first q|k|v operand) in one pass;
     // the same pass supplies the CLS rows (cls + pos[0], row frame * N) that the patch GEMM does not write
     {
@@ -857,14 +915,14 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
             const int wr[4] = {3 * Dv, Dv, c.enc_ffn, Dv}, wk[4] = {Dv, Dv, Dv, c.enc_ffn};
             if ((rc = stage_layer(h, s, ws, wr, wk, 4))) return rc;
         }
-        if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, Dv, L.qkvw, L.qkvb, Mp, 3 * Dv, Dv, h->qkv, 3 * Dv))) return rc;
+        if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, Dv, L.qkvw, L.qkvb, rows, Mp, 3 * Dv, Dv, h->qkv, 3 * Dv))) return rc;
         {
             ProfScope ps(h, GITCAP_PROF_ATTN_FULL, s, 4.0 * nf * c.enc_heads * (double)N * N * 64, 0.0);
             HIP_OK(h, launch_attn_full(h->qkv, h->ctx, nf, N, c.enc_heads, s));
         }
         if ((rc = gemm_ln(h, s, false, h->ctx, Dv, L.projw, L.projb, Mp, Dv, Dv, h->x, h->x, L.ln2w, L.ln2b, c.enc_ln_eps, rows,
                           h->hb, nullptr))) return rc;
-        if ((rc = gemm(h, s, EPI_BIAS_QGELU_BF16, h->hb, Dv, L.fc1w, L.fc1b, Mp, c.enc_ffn, Dv, h->ffn, c.enc_ffn))) return rc;
+        if ((rc = gemm(h, s, EPI_BIAS_QGELU_BF16, h->hb, Dv, L.fc1w, L.fc1b, rows, Mp, c.enc_ffn, Dv, h->ffn, c.enc_ffn))) return rc;
         if (i + 1 < c.enc_layers) {
             const EncLayer& Nx = h->enc[i + 1];
             if ((rc = gemm_ln(h, s, false, h->ffn, c.enc_ffn, L.fc2w, L.fc2b, Mp, Dv, c.enc_ffn, h->x, h->x, Nx.ln1w, Nx.ln1b,
@@ -885,6 +943,7 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
 int gitcap_set_visual(gitcap_t* h, const float* visual, int B, int S_img, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "set_visual: null handle");
     GUARD(h);
+    POLL(h);
     if (!h->finalized) return fail(h, GITCAP_ERR_STATE, "weights not finalized");
     select_slot(h, 0);
     if (!visual || B <= 0 || S_img <= 0) return fail(h, GITCAP_ERR_ARG, "set_visual: bad arguments");
@@ -901,6 +960,7 @@ int gitcap_text_forward(gitcap_t* h, const int64_t* ids, int ld_ids, int rows, i
                         float* logits_out, int all_positions, int64_t* argmax_out, int ld_argmax, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "text_forward: null handle");
     GUARD(h);
+    POLL(h);
     select_slot(h, 0);
     HIP_OK(h, join_async(h, (hipStream_t)stream));
     return text_forward(h, ids, ld_ids, rows, beams, t0, T, logits_out, all_positions, argmax_out, ld_argmax, nullptr, 0,
@@ -937,6 +997,7 @@ int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, i
                   int32_t* steps_out, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "greedy: null handle");
     GUARD(h);
+    POLL(h);
     int rc = greedy_check(h, max_len, stop, ids_out);
     if (rc) return rc;
     select_slot(h, 0);
@@ -948,6 +1009,7 @@ int gitcap_greedy(gitcap_t* h, const float* frames, int B, int F, int max_len, i
 int gitcap_encode_raw(gitcap_t* h, const uint8_t* frames_hwc_bgr, int B, int F, int H, int W, float* visual_out, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "encode_raw: null handle");
     GUARD(h);
+    POLL(h);
     select_slot(h, 0);
     HIP_OK(h, join_async(h, (hipStream_t)stream));
     return encode_impl(h, FrameSrc{nullptr, frames_hwc_bgr, H, W}, B, F, visual_out, (hipStream_t)stream);
@@ -957,6 +1019,7 @@ int gitcap_greedy_raw(gitcap_t* h, const uint8_t* frames_hwc_bgr, int B, int F, 
                       int64_t* ids_out, int32_t* steps_out, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "greedy_raw: null handle");
     GUARD(h);
+    POLL(h);
     int rc = greedy_check(h, max_len, stop, ids_out);
     if (rc) return rc;
     select_slot(h, 0);
@@ -969,6 +1032,7 @@ int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max
                          int32_t* steps_out, void* stream, int* ticket) {
     if (!h || !ticket) return fail(h, GITCAP_ERR_ARG, "greedy_submit: null argument");
     GUARD(h);
+    POLL(h);
     int rc = greedy_check(h, max_len, stop, ids_out);
     if (rc) return rc;
     const int slot = ticket_slot(h->next_ticket, gitcap::NSLOT);
@@ -996,6 +1060,7 @@ int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max
 int gitcap_greedy_wait(gitcap_t* h, int ticket, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "greedy_wait: null handle");
     GUARD(h);
+    POLL(h);
     if (!ticket_waitable(ticket, h->next_ticket, gitcap::NSLOT))
         return fail(h, GITCAP_ERR_ARG, "greedy_wait: ticket is not one of the submissions in flight");
     HIP_OK(h, hipStreamWaitEvent((hipStream_t)stream, h->slots[ticket_slot(ticket, gitcap::NSLOT)].ev_dec, 0));
@@ -1006,6 +1071,7 @@ int gitcap_beam_search(gitcap_t* h, const float* frames, int B, int F, int beams
                        int per_node_beam_size, int64_t* decoded_out, float* logprobs_out, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "beam_search: null handle");
     GUARD(h);
+    POLL(h);
     if (!decoded_out || !logprobs_out || beams < 1 || per_node_beam_size < 1) return fail(h, GITCAP_ERR_ARG, "beam_search: bad arguments");
     if (beams > h->c.max_beams || beams > 16 || beams * per_node_beam_size > 16)
         return fail(h, GITCAP_ERR_ARG, "beam_search: beams exceed max_beams / 16 candidates");
@@ -1042,6 +1108,7 @@ int gitcap_beam_search(gitcap_t* h, const float* frames, int B, int F, int beams
 int gitcap_reorder_rows(gitcap_t* h, const int32_t* src_rows, int rows, int t_len, void* stream) {
     if (!h) return fail(h, GITCAP_ERR_ARG, "reorder_rows: null handle");
     GUARD(h);
+    POLL(h);
     if (!src_rows || rows <= 0 || rows > h->R || t_len < 0 || t_len > h->Tmax)
         return fail(h, GITCAP_ERR_ARG, "reorder_rows: bad arguments");
     hipStream_t s = (hipStream_t)stream;
@@ -1050,6 +1117,12 @@ int gitcap_reorder_rows(gitcap_t* h, const int32_t* src_rows, int rows, int t_le
                                      (size_t)h->R * h->Tmax * 3 * h->D, s));
     std::swap(h->kv_txt, h->kv_txt2);
     return 0;
+}
+
+int gitcap_poll_errors(gitcap_t* h) {
+    if (!h) return GITCAP_ERR_ARG;
+    GUARD(h);
+    return poll_exchange(h);
 }
 
 int gitcap_profile_enable(gitcap_t* h, int enable) {
@@ -1154,7 +1227,8 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
 // Speed-only switches at run time (the same ones the GITCAP_* environment variables set once per process): lets ONE process
 // check that results do not depend on them.  key 0: GEMM + LayerNorm epilogue on/off, 1: one/two-row prologue on/off,
 // 2: 256-tile threshold (GITCAP_GEMM_SMALL_TILES), 3: 128-tile threshold (GITCAP_GEMM_TINY_TILES), 4: 224-row tiles on/off,
-// 5: greedy loop chains token steps (the arg-max launch embeds the next step's input rows) on/off.
+// 5: greedy loop chains token steps (the arg-max launch embeds the next step's input rows) on/off,
+// 6: polls a fused GEMM + LayerNorm tile waits for its siblings before it gives up (0 = default; 1 forces the fail-soft path).
 // Returns the old value.
 int gitcap_dbg_config(int key, int value) {
     int old = -1;
@@ -1165,6 +1239,7 @@ int gitcap_dbg_config(int key, int value) {
         case 3: old = g_tiny_tiles.exchange(value); break;
         case 4: old = g_tile224.exchange(value != 0); break;
         case 5: old = g_chain_steps.exchange(value != 0); break;
+        case 6: old = (int)g_ln_spin_limit.exchange((unsigned)(value > 0 ? value : 0)); break;
         default: return GITCAP_ERR_ARG;
     }
     return old;

@@ -85,6 +85,23 @@ int main() {
             CHECK(bm == 224 || bm == 256);
             CHECK(tile_rounds_cost(rows, N >> 8, bm, N <= 1024) <= tile_rounds_cost(rows, N >> 8, 256, N <= 1024));
         }
+    // a partitioned device (fewer CUs): the row-block map is used as soon as the grid exceeds THOSE, never fewer rounds than tiles / CUs
+    CHECK(ln_use_rowblock_map(74, 3, 128) && !ln_use_rowblock_map(40, 3, 128) && ln_use_rowblock_map(11, 3, 32));
+    for (int cus : {32, 64, 128, 256, 304})
+        for (int rows = 1; rows < 70000; rows += 193)
+            for (int N : {768, 1024, 3072}) {
+                const int bm = pick_tile_rows(rows, N, N <= 1024, cus);
+                CHECK(bm == 224 || bm == 256);
+                CHECK(tile_rounds_cost(rows, N >> 8, bm, N <= 1024, cus) * (long)cus >= (long)((rows + bm - 1) / bm) * (N >> 8) * bm);       // rounds >= tiles / CUs
+            }
+    // exchange health: a clean word changes nothing; a raised one degrades the handle for good and is reported every time it is seen
+    {
+        ExchangeHealth hs;
+        CHECK(!exchange_poll(hs, 0u) && !hs.degraded && hs.trips == 0);
+        CHECK(exchange_poll(hs, 1u) && hs.degraded && hs.trips == 1);
+        CHECK(!exchange_poll(hs, 0u) && hs.degraded && hs.trips == 1);          // the caller cleared the word: quiet again, still degraded
+        CHECK(exchange_poll(hs, 7u) && hs.degraded && hs.trips == 2);
+    }
     CHECK(pad_to(18912, 256) == 18944 && pad_to(256, 256) == 256 && pad_to(1, 16) == 16);
     std::puts("host_asan_test ok");
     return 0;

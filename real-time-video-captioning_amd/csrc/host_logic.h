@@ -138,7 +138,9 @@ GITCAP_HD inline int ln_grid_size(int nrb, int ntn) { return 8 * ntn * ((nrb + 7
 // rounds.  A grid that fits the chip is co-resident whatever the map and keeps the plain XCD remap, whose even spread
 // (222 tiles: 28 / 27 per XCD) leaves every XCD free CUs for the token-loop kernels of the other streams: handing XCDs
 // whole row blocks there (30 / 27) cost the pipelined bench 5 % (1651 vs 1742 captions/s, same box, round 3).
-inline bool ln_use_rowblock_map(int nrb, int ntn) { return nrb * ntn > 256; }
+// `cus` = compute units of the device the launch goes to (hipDeviceProp_t::multiProcessorCount, device_cus() in kernels.h:
+// 256 on a whole MI355X, fewer on a partitioned one).
+inline bool ln_use_rowblock_map(int nrb, int ntn, int cus = 256) { return nrb * ntn > cus; }
 GITCAP_HD inline bool ln_tile_of_block(int bid, int nrb, int ntn, int* tm, int* tn) {
     const int xcd = bid & 7, slot = bid >> 3;
     const int c = nrb >> 3, r = nrb & 7;
@@ -153,12 +155,33 @@ GITCAP_HD inline bool ln_tile_of_block(int bid, int nrb, int ntn, int* tm, int* 
 // One workgroup per CU, 256 CUs: a launch runs in whole rounds, so its K-loop time goes as rounds x tile rows.  224-row
 // tiles turn the bench shape's 0.87 / 2.6 / 3.47 rounds of 256-row tiles into 1 / 3 / 4 full rounds of 7/8 the work
 // (gemm_mt.hip).  Speed only: both heights give the same bits.
-inline long tile_rounds_cost(int rows, int ntn, int bm, bool ln) {
+inline long tile_rounds_cost(int rows, int ntn, int bm, bool ln, int cus = 256) {
     const int nrb = (rows + bm - 1) / bm, tiles = nrb * ntn;
-    long rounds = (tiles + 255) / 256;
-    if (ln && tiles > 256) rounds = (((nrb + 7) >> 3) * ntn + 31) / 32;      // whole row blocks per XCD, 32 CUs each
+    const int per_xcd = cus >= 8 ? cus / 8 : 1;                               // the workgroup -> tile maps deal over 8 dispatch sequences
+    long rounds = (tiles + cus - 1) / cus;
+    if (ln && tiles > cus) rounds = (((nrb + 7) >> 3) * ntn + per_xcd - 1) / per_xcd;   // whole row blocks per XCD
     return rounds * bm;
 }
-inline int pick_tile_rows(int rows, int N, bool ln) {
-    return tile_rounds_cost(rows, N >> 8, 224, ln) < tile_rounds_cost(rows, N >> 8, 256, ln) ? 224 : 256;
+inline int pick_tile_rows(int rows, int N, bool ln, int cus = 256) {
+    return tile_rounds_cost(rows, N >> 8, 224, ln, cus) < tile_rounds_cost(rows, N >> 8, 256, ln, cus) ? 224 : 256;
+}
+
+// ---- health of the GEMM + LayerNorm statistics exchange -------------------------------------------------------------------
+// A tile of a fused launch waits (bounded) for the sibling tiles of its row block; if the bound is ever hit -- the siblings
+// cannot become resident, e.g. a foreign process or a CU-masked stream holds the CUs (co-residency) -- the
+// kernel does not trap: it raises a word in host-visible memory and finishes with undefined LayerNorm output.  The host
+// reads the word at every entry point (and in gitcap_poll_errors): once raised, the launches issued since the last clean
+// check are suspect, the handle switches for good to GEMM + row-kernel launches (same bits, no exchange) and the entry
+// point returns GITCAP_ERR_EXCHANGE so that the caller re-runs what it had in flight.
+struct ExchangeHealth {
+    bool degraded = false;      // fused epilogues switched off for this handle
+    int trips = 0;              // times the flag was found raised
+};
+// flag = the value read from the host-visible word.  Returns true when the caller must reset (sync, clear the word and the
+// exchange barriers) and report GITCAP_ERR_EXCHANGE.
+inline bool exchange_poll(ExchangeHealth& hs, unsigned flag) {
+    if (!flag) return false;
+    hs.degraded = true;
+    ++hs.trips;
+    return true;
 }

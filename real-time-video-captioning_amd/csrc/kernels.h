@@ -35,7 +35,11 @@ struct GemmArgs {
     unsigned* ln_cnt;             // [row blocks][2] per row block {arrivals, generation}: zero before the first launch, self-resetting
     int ln_stats_rows;            // rows of ln_stats (>= M)
     int ln_rowblock_map;          // set by the launcher: workgroup -> tile map hands every XCD whole row blocks (host_logic.h)
+    unsigned* ln_fail;            // nullable: host-visible word raised when a tile gave up waiting for its siblings (no trap)
+    unsigned ln_spin_limit;       // polls (~0.3 us each) before giving up; 0 = the default (~30 s)
 };
+constexpr unsigned LN_SPIN_DEFAULT = 1u << 26;
+int device_cus();                 // compute units of the current device (cached per device; 256 when the query fails)
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);      // 128x128 tile (any M%128, N%128)
 hipError_t launch_gemm64(const GemmArgs& a, int epi, hipStream_t s);    // 64x64 tile, 3-stage ring (few-hundred-row launches)
 bool gemm256_ok(const GemmArgs& a);
@@ -113,6 +117,7 @@ struct TxtBlockArgs {
     unsigned* cnt;                              // [M] arrival tickets (zero between launches)
     float* xs; bf16_t* xsb;                     // out: x1 [M][D] fp32 and bf16 (xs may alias xin)
     int Mh;                                     // set by the launcher
+    int hm;                                     // experiment switch (txtblock.hip)
     int nt_kv;                                  // 1: the K/V rows are streamed with non-temporal loads (they do not fit the caches anyway)
 };
 bool txt_block_ok(int D);

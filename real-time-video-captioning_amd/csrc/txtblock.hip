@@ -121,7 +121,11 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
 
     const int Lk = a.S_img + tq + 1;
     const int sub = lane & 7, kk = lane >> 3;
-    const bf16_t* img = a.kv_img + (size_t)clip * a.S_img * ld + D + head * 64 + sub * 8;
+    // EXPERIMENT (GITCAP_TXT_HM=1, timing only -- the data read is not the K/V): image keys addressed as if the cache were
+    // head-major [clip][head][key][K 64 | V 64], i.e. one contiguous 256-B record per key and a contiguous stream per unit
+    const int kstride = a.hm ? 128 : ld, voff = a.hm ? 64 : D;
+    const bf16_t* img = a.hm ? a.kv_img + ((size_t)(clip * H + head) * a.S_img) * 128 + sub * 8
+                             : a.kv_img + (size_t)clip * a.S_img * ld + D + head * 64 + sub * 8;
     const bf16_t* txt = a.kv_txt + (size_t)r * a.Tmax * ld + D + head * 64 + sub * 8;
     char* mypre = kvpre + wid * 8192;
     // group 0 of this wave (keys 32 wid .. +31) -> LDS, lane-linear (lane = kk*8 + sub, one 1-KiB piece per 8 keys)
@@ -130,13 +134,15 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
         for (int u = 0; u < 4; ++u) {
             int key = wid * 32 + u * 8 + kk;
             key = key < Lk ? key : 0;
-            const bf16_t* kp = key < a.S_img ? img + (size_t)key * ld : txt + (size_t)(key - a.S_img) * ld;
+            const bool isimg = key < a.S_img;
+            const bf16_t* kp = isimg ? img + (size_t)key * kstride : txt + (size_t)(key - a.S_img) * ld;
+            const bf16_t* vp = kp + (isimg ? voff : D);
             if (a.nt_kv) {
                 __builtin_amdgcn_global_load_lds(GLB_PTR(kp), LDS_PTR(mypre + u * 1024), 16, 0, 2);
-                __builtin_amdgcn_global_load_lds(GLB_PTR(kp + D), LDS_PTR(mypre + 4096 + u * 1024), 16, 0, 2);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(vp), LDS_PTR(mypre + 4096 + u * 1024), 16, 0, 2);
             } else {
                 __builtin_amdgcn_global_load_lds(GLB_PTR(kp), LDS_PTR(mypre + u * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(GLB_PTR(kp + D), LDS_PTR(mypre + 4096 + u * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(vp), LDS_PTR(mypre + 4096 + u * 1024), 16, 0, 0);
             }
         }
     };
@@ -163,13 +169,15 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
             int key = g0 + u * 8 + kk;
             valid[u] = key < Lk;
             key = valid[u] ? key : 0;
-            const bf16_t* kp = key < a.S_img ? img + (size_t)key * ld : txt + (size_t)(key - a.S_img) * ld;
+            const bool isimg = key < a.S_img;
+            const bf16_t* kp = isimg ? img + (size_t)key * kstride : txt + (size_t)(key - a.S_img) * ld;
+            const bf16_t* vp = kp + (isimg ? voff : D);
             if (a.nt_kv) {      // read once per launch and too large to stay cached: do not displace what the GEMMs re-read
                 kf[u] = __builtin_nontemporal_load((const bf16x8*)kp);
-                vf[u] = __builtin_nontemporal_load((const bf16x8*)(kp + D));
+                vf[u] = __builtin_nontemporal_load((const bf16x8*)vp);
             } else {
                 kf[u] = *(const bf16x8*)kp;
-                vf[u] = *(const bf16x8*)(kp + D);
+                vf[u] = *(const bf16x8*)vp;
             }
         }
     };
@@ -361,6 +369,8 @@ hipError_t launch_txt_block(const TxtBlockArgs& a_in, hipStream_t s) {
     TxtBlockArgs a = a_in;
     static const int nt = getenv("GITCAP_TXT_NT") ? atoi(getenv("GITCAP_TXT_NT")) : -1;    // A/B switch: 0 never, 1 always
     if (nt >= 0) a.nt_kv = nt;
+    static const int hm = getenv("GITCAP_TXT_HM") ? atoi(getenv("GITCAP_TXT_HM")) : 0;           // experiment: see the kernel
+    a.hm = hm;
     const int M = a.rows * a.T;
     if (M <= 0 || a.H * 64 != a.D || a.beams <= 0 || !a.xin) return hipErrorInvalidValue;
     // first "half" of the rows for heads 8..11 (H == 12 mapping): whole clips (all beams of a clip stay together)

@@ -33,6 +33,7 @@ SYMBOLS = {
     "gitcap_greedy_raw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gitcap_greedy_submit": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
     "gitcap_greedy_wait": (c_int, [c_void_p, c_int, c_void_p]),
+    "gitcap_poll_errors": (c_int, [c_void_p]),
     "gitcap_preprocess": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gitcap_beam_topk": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gitcap_beam_search": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
@@ -85,7 +86,16 @@ class GitcapError(RuntimeError):
     pass
 
 
+class GitcapExchangeTimeout(GitcapError):
+    """GITCAP_ERR_EXCHANGE: a fused GEMM + LayerNorm launch gave up waiting for its sibling workgroups.  The handle has
+    switched to unfused launches; results produced since the last clean check must be recomputed (include/gitcap.h)."""
+
+
+ERR_EXCHANGE = -5
+
+
 def check(lib, handle, rc: int, what: str) -> None:
     if rc != 0:
         msg = lib.gitcap_last_error(handle)
-        raise GitcapError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")
+        cls = GitcapExchangeTimeout if rc == ERR_EXCHANGE else GitcapError
+        raise cls(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")

@@ -149,6 +149,25 @@ class GitCaptioner(nn.Module):
         rc = getattr(self._lib, name)(self._handle, *args)
         _lib.check(self._lib, self._handle, rc, name)
 
+    def poll_errors(self):
+        """Raises GitcapExchangeTimeout if a fused GEMM + LayerNorm launch gave up waiting since the last check
+        (gitcap_poll_errors, include/gitcap.h).  Meaningful after the stream that produced a result was synchronised."""
+        self._call("gitcap_poll_errors")
+
+    def _vouched(self, produce):
+        """Run `produce()` (which must end in a host synchronisation, e.g. a copy to the CPU) and vouch for its result:
+        if the exchange flag was raised meanwhile -- at entry, for earlier work, or by this very call -- the library has
+        switched to the unfused launches and the call is repeated once on those."""
+        try:
+            out = produce()
+            self.poll_errors()
+            return out
+        except _lib.GitcapExchangeTimeout:
+            self._inflight.clear()
+            out = produce()
+            self.poll_errors()
+            return out
+
     # ------------------------------------------------------------------ submissions in flight
     def _wait_submission(self, sub):
         """Make the current stream wait for a submission (once).  Its frames/ids/steps buffers are owned by the
@@ -377,6 +396,11 @@ class GitCaptioner(nn.Module):
         mode = {"all_sep": STOP_ALL_SEP, "never": STOP_NEVER}[stop]
         if max_len > self.max_text_len:
             raise ValueError(f"max_len {max_len} > max_text_len={self.max_text_len} the handle was created for")
+        if src.device.type == "cpu":              # CPU tensor in -> CPU ids out (real_time_inference.py:57): the copy back is a
+            return self._vouched(lambda: self._greedy_decode(src, max_len, mode))    # synchronisation, so the result is vouched for
+        return self._greedy_decode(src, max_len, mode)
+
+    def _greedy_decode(self, src, max_len, mode):
         self._drain()
         raw = src.dtype == torch.uint8            # camera frames [B,F,H,W,3] uint8 BGR: transform fused into the patch gather
         fr = self._raw_frames(src) if raw else self._frames(src)

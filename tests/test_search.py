@@ -3,12 +3,14 @@ the product's GeneratorWithBeamSearch + beam_topk kernel against that oracle."""
 import itertools
 import numpy as np
 import math
+import os
 
 import pytest
 import torch
 
 from oracle.search_oracle import beam_search as oracle_beam_search
 from oracle.search_oracle import top_k_top_p_filtering
+from oracle import search_oracle
 
 
 def _toy_step(V, seed):
@@ -270,3 +272,45 @@ def test_oracle_teacher_output_known_answer():
     assert np.array_equal(out[0, 0].numpy(), step0[2]) and np.array_equal(out[0, 1].numpy(), step1[3])
     # n is capped by the number of saved steps (model.py:772)
     assert teacher_output(pred, [step0], "w3 w1 w4").shape == (1, 1, V)
+
+
+def test_cfg4_exact_fixture_certificate():
+    """oracle/gen_golden_cfg4_beam.py: (1) the committed configs[4] fixture carries a certificate with a comfortable final
+    margin; (2) the certificate means what it says -- on the tiny config, a certified caption survives every search whose
+    candidate scores are perturbed by less than BAND / 2 (here: logits jittered so that 15 steps of log-softmax differences
+    add up to less than that)."""
+    import numpy as np
+    from gitcap.config import git_tiny
+    from gitcap.weights import synthetic_weights
+    from oracle.git_oracle import GitOracle, make_frames
+    from oracle.gen_golden_cfg4_beam import BAND, BEAMS, LENGTH_PENALTY, PER_NODE, STEPS, Reject, certify
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg4_beam_exact.npz"))
+    assert float(g["final_margin"]) >= 0.05 and float(g["band"]) == BAND and g["predictions"].shape == (1, STEPS)
+    assert int(g["predictions"][0, 0]) == 101 and int(g["beams"]) == BEAMS
+    cfg = git_tiny(2)
+    orc = GitOracle(cfg, synthetic_weights(cfg, 0), emulate_bf16=True)
+    accepted = 0
+    for seed in range(8):
+        fr = make_frames(1, 2, cfg.image_size, seed)
+        with torch.no_grad():
+            _, mem = orc.forward_image_enc(fr)
+            ikv = orc.image_kv(mem)
+
+            def step(t):
+                return orc.decoder_text(ikv, t, torch.zeros(t.shape[0], dtype=torch.long))[:, -1]
+            try:
+                c = certify(step, cfg)
+            except Reject:
+                continue
+            accepted += 1
+            gen = torch.Generator().manual_seed(seed)
+            amp = BAND / 2 / (2 * STEPS) * 0.95                  # |d log-softmax| <= 2 amp per step, summed over <= STEPS steps
+            for _ in range(12):
+                def noisy(t):
+                    l = step(t)
+                    return l + (torch.rand(l.shape, generator=gen) * 2 - 1) * amp
+                ids, _, _ = search_oracle.beam_search(torch.full((1, 1), cfg.cls_token_id), noisy, eos_index=cfg.sep_token_id,
+                                                      max_steps=STEPS, beam_size=BEAMS, per_node_beam_size=PER_NODE,
+                                                      length_penalty=LENGTH_PENALTY)
+                assert ids[0, :len(c["ids"])].tolist() == list(c["ids"]), (seed, ids, c)
+    assert accepted >= 1
