@@ -144,6 +144,101 @@ def cpu_baseline(cfg, weights, runs: int = 20, warmups: int = 3):
             "p50_latency_ms": round(med * 1e3, 1)}
 
 
+def other_configs(dev, note):
+    """The other BASELINE.json configurations and the reference's one real caller, under the same clock as the headline
+    (outside its timed region; parity-test cases otherwise): configs[1] (32 single frames, GIT-base), configs[4] (GIT-large,
+    10-frame clips, beam 4, 15 steps, src/models/model.py:702-708; B = 4 clips, e4m3 and bf16 weight storage) and the webcam
+    shape of src/real_time_inference.py:56-58 (one 6-frame clip, CPU tensor in, 25 tokens, CPU ids out)."""
+    from gitcap.config import git_base, git_large
+    from gitcap.model import GitCaptioner
+    from gitcap.weights import quantize_weights_fp8, synthetic_weights
+
+    def med_ms(fn, n=7, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize(dev)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return sorted(ts)[len(ts) // 2]
+
+    out = {}
+    # ---- configs[1]: batch = 32 single-frame image captioning, GIT-base, 20 greedy tokens ----
+    cfg = git_base(0)
+    w = synthetic_weights(cfg, seed=0)
+    m = GitCaptioner(cfg, w, device=dev, max_batch=32, max_frames=1, max_text_len=TOKENS, stop="never")
+    g = torch.Generator(device="cpu").manual_seed(99)
+    ins = [torch.randn(32, 1, 3, cfg.image_size, cfg.image_size, generator=g).to(dev) for _ in range(2)]
+    k = [0]
+
+    def one():
+        k[0] += 1
+        return m.greedy_decode(ins[k[0] % 2], max_len=TOKENS, stop="never")
+    ser = med_ms(one)
+
+    def pipe(n):
+        pend = []
+        for i in range(n):
+            pend.append(m.greedy_decode_async(ins[i % 2], max_len=TOKENS, stop="never"))
+            if len(pend) == 4:
+                pend.pop(0).result()
+        while pend:
+            pend.pop(0).result()
+    pipe(4)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    pipe(16)
+    torch.cuda.synchronize(dev)
+    pp = (time.perf_counter() - t0) / 16 * 1e3
+    t1 = med_ms(lambda: m.greedy_decode(ins[0], max_len=1, stop="never"), n=5)
+    loop = (ser - t1) * TOKENS / (TOKENS - 1)
+    db = decode_phase_bytes(cfg, 32, 1, TOKENS)
+    out["configs[1]"] = {"workload": "32 single 224x224 frames, GIT-base, 20 greedy tokens, EOS disabled",
+                         "serial_ms_per_batch": round(ser, 3), "serial_captions_per_s": round(32e3 / ser, 1),
+                         "pipelined_ms_per_batch": round(pp, 3), "pipelined_captions_per_s": round(32e3 / pp, 1),
+                         "gflop_per_caption": 55.6, "pipelined_mfma_frac": round(32e3 / pp * 55.6 / 1e3 / MFMA_PEAK_TFLOPS, 4),
+                         "decode_phase_ms": round(loop, 3), "decode_phase_hbm_frac": round(db / (loop * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    del m
+    note("other_configs: configs[1] done")
+    # ---- the webcam shape: one clip, CPU in / CPU out, 25 tokens (real_time_inference.py:56-58) ----
+    cfg = git_base(FRAMES)
+    m = GitCaptioner(cfg, synthetic_weights(cfg, seed=0), device=dev, max_batch=1, max_frames=FRAMES, max_text_len=25, stop="never")
+    clip = torch.randn(1, FRAMES, 3, cfg.image_size, cfg.image_size, generator=g)
+    cpu_io = med_ms(lambda: m.greedy_decode(clip, max_len=25, stop="never"), n=9)
+    clip_d = clip.to(dev)
+    dev20 = med_ms(lambda: m.greedy_decode(clip_d, max_len=TOKENS, stop="never"), n=9)
+    out["one_clip"] = {"workload": "1 clip x 6 frames, GIT-base; the reference's caller (src/real_time_inference.py:56-58)",
+                       "cpu_in_cpu_out_25_tokens_ms": round(cpu_io, 3), "device_resident_20_tokens_ms": round(dev20, 3)}
+    del m
+    note("other_configs: one clip done")
+    # ---- configs[4]: GIT-large, 10-frame clips, beam 4, 15 steps, device-resident search; B = 4 clips ----
+    cfg = git_large(10)
+    B, beams, steps = 4, 4, 15
+    wq = quantize_weights_fp8(synthetic_weights(cfg, seed=0))
+    fr = torch.randn(B, 10, 3, cfg.image_size, cfg.image_size, generator=g).to(dev)
+    D, V, Ld, S = cfg.dec_width, cfg.vocab_size, cfg.dec_layers, 10 * cfg.tokens_per_frame
+    c4 = {"workload": "GIT-large (ViT-L/14), 4 clips x 10 frames, beam 4, 15 steps, e4m3-valued weights, device-resident search",
+          "gflop_per_caption": 1975.0}
+    for storage in ("fp8_e4m3", "bf16"):
+        m = GitCaptioner(cfg, wq, device=dev, max_batch=B, max_frames=10, max_text_len=20, max_beams=beams, weight_dtype=storage)
+        dt = med_ms(lambda: m.infer(fr, beam_size=beams, max_steps=steps), n=5)
+        di = med_ms(lambda: m.forward_image_enc(fr), n=5)
+        wbytes = (Ld * (4 * D * D + 2 * D * cfg.dec_ffn) + D * V) * (1.0 if storage == "fp8_e4m3" else 2.0)
+        kv = sum(B * beams * Ld * 2 * (S + t + 1) * D * 2.0 for t in range(steps - 1))
+        lp = dt - di
+        c4[storage] = {"ms_per_batch": round(dt, 3), "captions_per_s": round(B * 1e3 / dt, 1),
+                       "mfma_frac": round(B * 1e3 / dt * 1975.0 / 1e3 / MFMA_PEAK_TFLOPS, 4), "image_pass_ms": round(di, 3),
+                       "search_loop_ms": round(lp, 3), "search_loop_hbm_frac": round(((steps - 1) * wbytes + kv) / (lp * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "weight_mbytes": round(m.weight_bytes() / 1e6, 1)}
+        del m
+        note(f"other_configs: configs[4] {storage} done")
+    out["configs[4]"] = c4
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,6 +246,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is repeated; the median repeat is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip configs[1] / configs[4] / one-clip (reported beside the headline)")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event instrumented pass")
     ap.add_argument("--plain", action="store_true", help="only warm-up + the timed region (for rocprofv3 runs: every pass in the trace is one full step)")
     ap.add_argument("--serial", action="store_true", help="one batch at a time (no cross-batch pipelining)")
@@ -166,6 +262,23 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU); see module docstring")
+    phase = ["start", time.time()]
+
+    def note(msg):
+        phase[0], phase[1] = msg, time.time()
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    def heartbeat():            # a run that stops making progress says where, and ends with a status instead of a silent kill
+        while True:
+            time.sleep(30)
+            stuck = time.time() - phase[1]
+            print(f"[bench] rank {rank} alive: {stuck:.0f} s since '{phase[0]}'", file=sys.stderr, flush=True)
+            if stuck > 600:
+                print(f"[bench] rank {rank}: no progress for 10 minutes after '{phase[0]}', giving up", file=sys.stderr, flush=True)
+                os._exit(4)
+    import threading
+    threading.Thread(target=heartbeat, daemon=True).start()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -256,9 +369,6 @@ def main():
         assert out.shape == (world * CLIPS_PER_GPU, TOKENS + 1)
         return el, p
 
-    def note(msg):
-        if rank == 0:
-            print(f"[bench] {msg}", file=sys.stderr, flush=True)
     note("warm-up done")
     regions = sorted(timed_region() for _ in range(max(1, args.repeats)))
     note("timed regions done")
@@ -404,6 +514,10 @@ def main():
         roofline["gemm_ln_hbm_frac"] = be[1]["hbm_frac"]
         roofline["attn_full_mfma_frac"] = roofline["classes"]["attn_full"]["frac"]
 
+    others = None
+    if rank == 0 and world == 1 and not args.plain and not args.no_other_configs:
+        del model
+        others = other_configs(dev, note)
     note("GPU measurements done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -424,7 +538,7 @@ def main():
                        "parallelism": f"dp{world}", "batches_in_flight": 1 if args.serial else args.inflight * args.coalesce, "coalesce": args.coalesce, "collective": "all_gather(int64[16,21]) per step" if use_dist else "none", "distinct_input_batches": NIN},
             "caption_mfma_frac": round(value / world * GFLOP_PER_CAPTION / 1e3 / MFMA_PEAK_TFLOPS, 4),
             "pipelined_equals_serial": pipelined_equals_serial,
-            "serial": serial, "roofline": roofline, "cpu_baseline": cpu, "breakdown": breakdown,
+            "serial": serial, "roofline": roofline, "cpu_baseline": cpu, "other_configs": others, "breakdown": breakdown,
         }
         if pipelined_equals_serial is False:
             # the timed path returned different captions than one batch at a time: the number is not a measurement

@@ -1,0 +1,130 @@
+// Feed-forward sub-layer of the GIT decoder for TEXT rows (a decode step's handful of rows, or rows x T teacher-forced
+// positions), fused over hidden slices:
+//
+//     h = GELU(x W1^T + b1)  (bf16)          slab[s] = h[:, 64 s .. 64 s + 63] . W2[:, 64 s .. 64 s + 63]^T  (fp32)
+//
+// One 4-wave workgroup owns 64 hidden units.  Wave w computes 16 of them for the 16 rows of an m-tile (full K = D, the
+// 16x16x32 MFMA chain of skinny_full_kernel), rounds to bf16 exactly where the FC1 launch did and leaves them in LDS;
+// after one barrier every wave multiplies the 16 x 64 tile of h into its quarter of the D output columns (two k-steps per
+// 16-column tile) and writes its fp32 partial.  The dec_ffn / 64 slabs are summed in a fixed order by ln_reduce_kernel
+// (rowops.hip) or by the row prologue of the next layer's q|k|v launch (rowln.h), with bias + residual + LayerNorm.
+//
+// What it replaces: the FC1 + GELU launch (192 single-wave workgroups, h through HBM) and the FC2 split-K launch (384):
+// one dependent stage (~5 us) of every decoder layer of every token step.  What makes it possible: the fragment-major
+// weight copies (launch_pack_frags) -- a workgroup here pulls 192 KiB of weights by itself, 4 us in the row-major operand
+// pattern (47 GB/s per CU), 1.2-2.8 us from the packed copy (tools/probe/pull_probe.hip).  All fragments of a wave
+// (48 KiB) are requested before its first MFMA.
+//
+// No inter-workgroup dependency, no atomics; a row's arithmetic does not depend on M (batch invariant).  Bitwise equal to
+// launch_skinny(SK_BIAS_GELU_BF16) followed by launch_skinny_splitk(ksplit = F / 64): the same MFMA sequence per
+// element (tests/test_kernels_gpu.py; GITCAP_NO_FFN_FUSE / gitcap_dbg_config(7, 0) selects that pair of launches).
+#include "kernels.h"
+
+namespace {
+
+template <int K32, bool FP8>
+__global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
+    constexpr int D = K32 * 32;
+    constexpr int NT = (D / 16) / 4;                        // FC2 output tiles (16 columns) per wave
+    static_assert((D / 16) % 4 == 0, "D must be a multiple of 64");
+    __shared__ __attribute__((aligned(16))) bf16_t hs[2][16][72];     // h of one m-tile (two buffers), row pitch 144 B
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int s = blockIdx.x;
+    const int F32 = a.F >> 5;
+
+    // ---- every weight fragment of the wave, requested back to back: 16 hidden rows of W1 (K32 k-steps), then the two
+    //      k-steps (hidden 64 s .. + 63) of its NT column tiles of W2
+    bf16x8 w1[K32], w2[NT][2];
+    {
+        const size_t f1 = (((size_t)s * 4 + wave) * K32) * 64 + lane;
+        const size_t f2 = (((size_t)wave * NT) * F32 + (size_t)s * 2) * 64 + lane;
+        if (FP8) {
+            const uint2 *p1 = (const uint2*)a.W1pk + f1, *p2 = (const uint2*)a.W2pk + f2;
+            uint2 r1[K32], r2[NT][2];
+#pragma unroll
+            for (int k = 0; k < K32; ++k) r1[k] = p1[(size_t)k * 64];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                r2[t][0] = p2[(size_t)t * F32 * 64];
+                r2[t][1] = p2[(size_t)t * F32 * 64 + 64];
+            }
+            const float sc1 = a.w1scale[(s * 4 + wave) * 16 + frow];
+#pragma unroll
+            for (int k = 0; k < K32; ++k) w1[k] = fp8x8_to_bf16x8(r1[k], sc1);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float sc2 = a.w2scale[(wave * NT + t) * 16 + frow];
+                w2[t][0] = fp8x8_to_bf16x8(r2[t][0], sc2);
+                w2[t][1] = fp8x8_to_bf16x8(r2[t][1], sc2);
+            }
+        } else {
+            const bf16x8 *p1 = (const bf16x8*)a.W1pk + f1, *p2 = (const bf16x8*)a.W2pk + f2;
+#pragma unroll
+            for (int k = 0; k < K32; ++k) w1[k] = p1[(size_t)k * 64];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                w2[t][0] = p2[(size_t)t * F32 * 64];
+                w2[t][1] = p2[(size_t)t * F32 * 64 + 64];
+            }
+        }
+    }
+    const int nh = s * 64 + wave * 16 + fq * 4;             // this lane's 4 hidden units
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = a.b1[nh + r];
+    float* slab = a.slabs + (size_t)s * a.M * D;
+
+    const int mtiles = (a.M + 15) >> 4;
+    for (int mt = 0; mt < mtiles; ++mt) {
+        int m = mt * 16 + frow;
+        const bool mvalid = m < a.M;
+        m = mvalid ? m : a.M - 1;                            // clamp: padded rows are discarded
+        // ---- FC1 + GELU: h[m][nh .. nh + 3] -> LDS (bf16) ----
+        const bf16_t* xp = a.X + (size_t)m * a.ldx + fq * 8;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < K32; ++k) {
+            const bf16x8 xf = *(const bf16x8*)(xp + k * 32);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[k], xf, acc, 0, 0, 0);
+        }
+        uint2 hv;
+        hv.x = pack_bf2(erf_gelu(acc[0] + bias[0]), erf_gelu(acc[1] + bias[1]));
+        hv.y = pack_bf2(erf_gelu(acc[2] + bias[2]), erf_gelu(acc[3] + bias[3]));
+        bf16_t (*hb)[72] = hs[mt & 1];
+        *(uint2*)(&hb[frow][wave * 16 + fq * 4]) = hv;
+        // one barrier per m-tile: buffer (mt + 1) & 1 is rewritten only after every wave has passed this barrier, i.e. after
+        // it finished reading that buffer in iteration mt - 1
+        __syncthreads();
+        // ---- FC2 share of the slice: out[m][n] for the wave's NT tiles ----
+        const bf16x8 h0 = *(const bf16x8*)(&hb[frow][fq * 8]), h1 = *(const bf16x8*)(&hb[frow][32 + fq * 8]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[t][0], h0, o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[t][1], h1, o, 0, 0, 0);
+            if (mvalid) *(f32x4*)(slab + (size_t)m * D + (wave * NT + t) * 16 + fq * 4) = o;
+        }
+    }
+}
+
+}  // namespace
+
+bool ffn_txt_ok(int D, int F) { return (D == 128 || D == 768) && F > 0 && F % 64 == 0; }
+
+hipError_t launch_ffn_txt(const FfnTxtArgs& a, hipStream_t s) {
+    if (!ffn_txt_ok(a.D, a.F) || a.M <= 0 || !a.X || !a.W1pk || !a.W2pk || !a.b1 || !a.slabs || (a.ldx & 7) ||
+        ((a.w1scale == nullptr) != (a.w2scale == nullptr)))
+        return hipErrorInvalidValue;
+    const dim3 grid(a.F / 64);
+    const bool f8 = a.w1scale != nullptr;
+    if (a.D == 768) {
+        if (f8) hipLaunchKernelGGL((ffn_txt_kernel<24, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((ffn_txt_kernel<24, false>), grid, dim3(256), 0, s, a);
+    } else {
+        if (f8) hipLaunchKernelGGL((ffn_txt_kernel<4, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((ffn_txt_kernel<4, false>), grid, dim3(256), 0, s, a);
+    }
+    return hipGetLastError();
+}

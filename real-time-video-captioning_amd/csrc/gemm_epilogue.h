@@ -191,6 +191,9 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
         const unsigned limit = a.ln_spin_limit ? a.ln_spin_limit : LN_SPIN_DEFAULT;
         while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen) {
             __builtin_amdgcn_s_sleep(12);                   // ~0.3 us between polls: 200 spinning tiles must not load the fabric
+            // once ANY tile of ANY launch has given up (the host-visible word is up) nobody waits out the full bound again: the
+            // launches queued behind the first failure finish at once instead of 30 s each
+            if ((spins & 1023u) == 1023u && a.ln_fail && __hip_atomic_load(a.ln_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
             if (++spins > limit) {                          // ~30 s: far beyond any preemption of a sibling.  No trap: tell the
                 if (a.ln_fail) __hip_atomic_store(a.ln_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host and finish
                 break;                                      // (the rows of this block are undefined; host_logic.h: ExchangeHealth)

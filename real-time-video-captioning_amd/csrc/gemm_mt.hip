@@ -198,6 +198,9 @@ __device__ __forceinline__ void epilogue_tile_ln(const GemmArgs& a, const f32x4 
         const unsigned limit = a.ln_spin_limit ? a.ln_spin_limit : LN_SPIN_DEFAULT;
         while (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen) {
             __builtin_amdgcn_s_sleep(12);
+            // once ANY tile of ANY launch has given up (the host-visible word is up) nobody waits out the full bound again: the
+            // launches queued behind the first failure finish at once instead of 30 s each
+            if ((spins & 1023u) == 1023u && a.ln_fail && __hip_atomic_load(a.ln_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) break;
             if (++spins > limit) {                          // ~30 s: fail soft (gemm_epilogue.h; host_logic.h: ExchangeHealth)
                 if (a.ln_fail) __hip_atomic_store(a.ln_fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;

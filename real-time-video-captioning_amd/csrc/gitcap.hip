@@ -46,9 +46,12 @@ namespace {
 // a GEMM weight [Npad16][K]: bf16, or OCP e4m3 bytes + one power-of-two scale per row (scale != nullptr)
 struct WRef {
     const void* p = nullptr; const float* scale = nullptr;
-    // rows n0.. of the matrix (K columns)
+    const void* pk = nullptr;          // fragment-major copy for the weight-streaming text kernels (launch_pack_frags), or null
+    // rows n0.. of the matrix (K columns); n0 a multiple of 16
     WRef rows_from(size_t n0, size_t K) const {
-        WRef r; r.p = (const char*)p + n0 * K * (scale ? 1 : 2); r.scale = scale ? scale + n0 : nullptr; return r;
+        WRef r; r.p = (const char*)p + n0 * K * (scale ? 1 : 2); r.scale = scale ? scale + n0 : nullptr;
+        r.pk = pk ? (const char*)pk + n0 * K * (scale ? 1 : 2) : nullptr;      // whole 16-row tiles: the same byte offset
+        return r;
     }
 };
 struct EncLayer {
@@ -68,6 +71,7 @@ struct gitcap {
     mutable std::string err;
     std::map<std::string, DevTensor> w;
     std::map<std::string, float*> wscale;          // e4m3 storage: per-row scales of the GEMM weights
+    std::map<std::string, std::pair<void*, size_t>> wpack;   // fragment-major copies of the text-path weights (name -> buffer, bytes)
     bool finalized = false, fp8 = false;
     bf16_t* wstage = nullptr;                       // e4m3 storage: bf16 staging panel of a single GEMM
     bf16_t* lstage = nullptr;                       // e4m3 storage: bf16 staging of the (up to 4) matrices of one layer
@@ -95,6 +99,7 @@ struct gitcap {
     unsigned* ln_fail = nullptr;        // host-pinned word a fused launch raises when a tile gave up waiting (gemm_epilogue.h)
     ExchangeHealth xh;                  // host_logic.h: once raised, the handle runs GEMM + row kernel for good
     int cus = 256;                      // compute units of the handle's device
+    int nslab_max = 16;                 // fp32 split-K slabs per text row the workspace holds
     bf16_t *hb = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr, *patches = nullptr, *kv_img = nullptr;
     // workspace (text rows)
     float *xs = nullptr, *xs2 = nullptr, *slabs = nullptr, *part = nullptr, *amax_val = nullptr;
@@ -395,13 +400,15 @@ int skinny(gitcap* h, hipStream_t s, int epi, const bf16_t* X, int ldx, const WR
            int N, int K, void* out, int ldo, int T = 1, int row_stride = 1, int row_off = 0) {
     ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * M * N * K, (W.scale ? 1.0 : 2.0) * N * K);
     SkinnyArgs a{X, ldx, W.p, W.scale, bias, M, N, K, out, ldo, T, row_stride, row_off, nullptr, nullptr};
+    a.Wpk = W.pk;
     HIP_OK(h, launch_skinny(a, epi, s));
     return 0;
 }
 
-int skinny_splitk(gitcap* h, hipStream_t s, const bf16_t* X, int ldx, const WRef& W, int M, int N, int K, float* slabs) {
+int skinny_splitk(gitcap* h, hipStream_t s, const bf16_t* X, int ldx, const WRef& W, int M, int N, int K, float* slabs, int ksplit = 0) {
     ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * M * N * K, (W.scale ? 1.0 : 2.0) * N * K);
     SkinnyArgs a{X, ldx, W.p, W.scale, nullptr, M, N, K, slabs, N, 1, 1, 0, nullptr, nullptr};
+    a.Wpk = W.pk; a.ksplit = ksplit;
     HIP_OK(h, launch_skinny_splitk(a, s));
     return 0;
 }
@@ -462,6 +469,10 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
 // the next step's.  Same row code either way (rowln.h); one launch less per token step.  Only with more than two rows (with
 // one or two the q|k|v launch embeds its rows itself) and one position per row.
 std::atomic<bool> g_chain_steps{!env_flag("GITCAP_NO_STEP_CHAIN")};       // gitcap_dbg_config(5, .)
+// fragment-major copies of the text-path weights, made by gitcap_finalize_weights (GITCAP_NO_WPACK / gitcap_dbg_config(8, 0):
+// the kernels read the row-major originals; same bits, slower; the FFN then runs as two launches)
+std::atomic<bool> g_wpack{!env_flag("GITCAP_NO_WPACK")};
+std::atomic<bool> g_ffn_fuse{!env_flag("GITCAP_NO_FFN_FUSE")};            // gitcap_dbg_config(7, .): ffn_txt.hip vs FC1 + split-K FC2 launches
 
 bool text_chain_ok(gitcap* h, int rows, int T) {
     return g_chain_steps && T == 1 && !(h->want_hidden && h->cur_slot == 0) &&
@@ -482,7 +493,12 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     const int D = h->D, M = rows * T, H = c.dec_heads;
     int rc;
     const size_t kvi_layer = (size_t)h->Mi * 3 * D, kvt_layer = (size_t)h->R * h->Tmax * 3 * D;
-    const int ks_f = skinny_ksplit(c.dec_ffn);
+    // FC1 -> GELU -> FC2 of the text rows: one launch over 64-wide hidden slices (ffn_txt.hip), leaving dec_ffn / 64 fp32
+    // slabs; or (GITCAP_NO_FFN_FUSE / gitcap_dbg_config(7, 0): A-B and cross-check) the FC1 launch + the split-K FC2 launch
+    // over the same slabs -- the same bits either way
+    const bool ffn_slices = ffn_txt_ok(D, c.dec_ffn) && c.dec_ffn / 64 <= h->nslab_max;
+    const bool ffn_fused = ffn_slices && g_ffn_fuse && h->dec[0].fc1w.pk && h->dec[0].fc2w.pk;
+    const int ks_f = ffn_slices ? c.dec_ffn / 64 : skinny_ksplit(c.dec_ffn);
     const bool hid = h->want_hidden && h->cur_slot == 0 && t0 == 0;    // hidden-state export: a whole prefix, synchronous path
     auto keep_txt = [&](int entry) -> hipError_t {                       // xs = the text rows' input of layer `entry`
         return hid ? hipMemcpyAsync(h->hid_txt + (size_t)entry * h->Mt * D, h->xs, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s) : hipSuccess;
@@ -501,6 +517,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
         if (rows_pro) {
             ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * M * 3 * D * D, 2.0 * 3 * D * D);
             SkinnyArgs a{h->xsb, D, L.qkvw.p, nullptr, L.qkvb, M, 3 * D, D, kvt, 3 * D, T, h->Tmax, t0, nullptr, nullptr};
+            a.Wpk = L.qkvw.pk;
             if (l == 0) {
                 a.ln.kind = 2; a.ln.ids = ids; a.ln.ld_ids = ld_ids; a.ln.T = T; a.ln.t0 = t0; a.ln.vocab = c.vocab_size;
                 a.ln.word = h->word; a.ln.pos = h->tpos; a.ln.g = h->txt_lnw; a.ln.b = h->txt_lnb;
@@ -527,7 +544,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
             TxtBlockArgs ta{};
             ta.kv_img = h->kv_img + (size_t)l * kvi_layer; ta.kv_txt = kvt;
             ta.rows = rows; ta.beams = beams; ta.t0 = t0; ta.T = T; ta.Tmax = h->Tmax; ta.S_img = h->cur_S; ta.H = H; ta.D = D;
-            ta.aow = L.aow.p; ta.aoscale = L.aow.scale; ta.aob = L.aob; ta.g1 = L.ln1w; ta.b1 = L.ln1b; ta.xin = xcur; ta.eps = c.dec_ln_eps;
+            ta.aow = L.aow.p; ta.aowpk = L.aow.scale ? nullptr : L.aow.pk; ta.aoscale = L.aow.scale; ta.aob = L.aob; ta.g1 = L.ln1w; ta.b1 = L.ln1b; ta.xin = xcur; ta.eps = c.dec_ln_eps;
             ta.part = h->part; ta.cnt = h->row_cnt; ta.xs = xcur; ta.xsb = h->xsb;
             // K/V of all layers that one token step streams: beyond what the 256 MiB Infinity Cache can keep next to the
             // 132 MB of decoder weights, the rows are loaded non-temporally (16 clips x 6 frames: 349 MB per step; measured
@@ -538,8 +555,14 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
             ProfScope ps(h, GITCAP_PROF_ATTN_TEXT, s, 0.0, kvb + (L.aow.scale ? 1.0 : 2.0) * D * D);     // K/V read once + the output dense
             HIP_OK(h, launch_txt_block(ta, s));
         }
-        if ((rc = skinny(h, s, SK_BIAS_GELU_BF16, h->xsb, D, L.fc1w, L.fc1b, M, c.dec_ffn, D, h->fs, c.dec_ffn))) return rc;
-        if ((rc = skinny_splitk(h, s, h->fs, c.dec_ffn, L.fc2w, M, D, c.dec_ffn, h->slabs))) return rc;
+        if (ffn_fused) {
+            ProfScope ps(h, GITCAP_PROF_SKINNY, s, 4.0 * M * c.dec_ffn * D, (L.fc1w.scale ? 1.0 : 2.0) * 2.0 * c.dec_ffn * D);
+            FfnTxtArgs fa{h->xsb, D, L.fc1w.pk, L.fc2w.pk, L.fc1w.scale, L.fc2w.scale, L.fc1b, M, D, c.dec_ffn, h->slabs};
+            HIP_OK(h, launch_ffn_txt(fa, s));
+        } else {
+            if ((rc = skinny(h, s, SK_BIAS_GELU_BF16, h->xsb, D, L.fc1w, L.fc1b, M, c.dec_ffn, D, h->fs, c.dec_ffn))) return rc;
+            if ((rc = skinny_splitk(h, s, h->fs, c.dec_ffn, L.fc2w, M, D, c.dec_ffn, h->slabs, ffn_slices ? ks_f : 0))) return rc;
+        }
     }
     {   // the last layer's FC2 reduce + bias + residual + LayerNorm
         const DecLayer& P = h->dec[c.dec_layers - 1];
@@ -550,7 +573,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     // vocabulary head (+ arg-max partials per 16-column tile, reduced by argmax_final)
     const int V = c.vocab_size, ntiles = (V + 15) / 16;
     SkinnyArgs ha{};
-    ha.W = h->head_w.p; ha.wscale = h->head_w.scale; ha.bias = h->head_b; ha.N = V; ha.K = D; ha.ldo = V; ha.T = 1; ha.row_stride = 1; ha.row_off = 0;
+    ha.W = h->head_w.p; ha.Wpk = h->head_w.pk; ha.wscale = h->head_w.scale; ha.bias = h->head_b; ha.N = V; ha.K = D; ha.ldo = V; ha.T = 1; ha.row_stride = 1; ha.row_off = 0;
     int am_stride = 1, am_off = 0;
     if (all_positions && logits_out) {
         ha.X = h->xsb; ha.ldx = D; ha.M = M; ha.out = logits_out;
@@ -625,6 +648,7 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     h->R = c.max_batch * c.max_beams; h->Tmax = c.max_text_len;
     h->Mt = pad_to(h->R * h->Tmax, 16);
     const int Dm = std::max(h->Dv, h->D), Fm = std::max(c.enc_ffn, c.dec_ffn);
+    h->nslab_max = std::max(16, std::min(64, c.dec_ffn / 64));    // FC2 partial slabs per text row: dec_ffn / 64 hidden slices (ffn_txt.hip)
     int rc = 0;
     const size_t Mi = h->Mi, Mt = h->Mt;
     rc = rc ? rc : ws_alloc(h, &h->x, Mi * Dm);
@@ -650,7 +674,7 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
         rc = rc ? rc : ws_alloc(h, &sl.sep_cnt, (size_t)h->Tmax + 1);
         rc = rc ? rc : ws_alloc(h, &sl.xs, Mt * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.xs2, 2 * h->D);            // second copy of the residual rows for the one/two-row form
-        rc = rc ? rc : ws_alloc(h, &sl.slabs, (size_t)16 * Mt * h->D);
+        rc = rc ? rc : ws_alloc(h, &sl.slabs, (size_t)h->nslab_max * Mt * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.xsb, Mt * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.part, Mt * (size_t)c.dec_heads * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.row_cnt, Mt);
@@ -730,6 +754,8 @@ void gitcap_destroy(gitcap_t* h) {
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto& kv : h->wscale)
         if (kv.second) (void)hipFree(kv.second);
+    for (auto& kv : h->wpack)
+        if (kv.second.first) (void)hipFree(kv.second.first);
     delete h;
 }
 
@@ -843,6 +869,39 @@ int gitcap_finalize_weights(gitcap_t* h) {
         L.qkvw = Wt(p + "qkv.w"); L.qkvb = F(p + "qkv.b"); L.aow = Wt(p + "ao.w"); L.aob = F(p + "ao.b");
         L.ln1w = F(p + "ln1.w"); L.ln1b = F(p + "ln1.b"); L.fc1w = Wt(p + "fc1.w"); L.fc1b = F(p + "fc1.b");
         L.fc2w = Wt(p + "fc2.w"); L.fc2b = F(p + "fc2.b"); L.ln2w = F(p + "ln2.w"); L.ln2b = F(p + "ln2.b");
+    }
+    // fragment-major copies of the matrices the token loop streams (decoder layers + vocabulary head): what a lane of the
+    // text kernels loads per k-step becomes contiguous, a wave instruction reads 1 KiB in one piece (rowops.hip:
+    // pack_frags_kernel; 3-4 x the per-CU pull rate).  The image pass keeps reading the row-major originals.
+    for (auto& L : h->dec) L.qkvw.pk = L.aow.pk = L.fc1w.pk = L.fc2w.pk = nullptr;
+    h->head_w.pk = nullptr;
+    if (g_wpack) {
+        auto pack = [&](const std::string& n, WRef& r) -> int {
+            const DevTensor& t = h->w[n];
+            const int rows16 = pad_to((int)t.shape[0], 16), K = (int)t.shape[1];
+            const size_t bytes = (size_t)rows16 * K * (r.scale ? 1 : 2);
+            auto& slot = h->wpack[n];
+            if (slot.first && slot.second != bytes) { (void)hipFree(slot.first); h->ws_bytes -= (int64_t)slot.second; slot = {nullptr, 0}; }
+            if (!slot.first) {
+                if (hipMalloc(&slot.first, bytes) != hipSuccess) return fail(h, GITCAP_ERR_NOMEM, "finalize: hipMalloc (packed weights)");
+                slot.second = bytes;
+                h->ws_bytes += (int64_t)bytes;
+            }
+            HIP_OK(h, launch_pack_frags(r.p, slot.first, rows16, K, r.scale ? 1 : 2, nullptr));
+            r.pk = slot.first;
+            return 0;
+        };
+        int rc = 0;
+        for (int i = 0; i < h->c.dec_layers && !rc; ++i) {
+            const std::string p = "dec.L" + std::to_string(i) + ".";
+            DecLayer& L = h->dec[i];
+            rc = pack(p + "qkv.w", L.qkvw);
+            rc = rc ? rc : pack(p + "ao.w", L.aow);
+            rc = rc ? rc : pack(p + "fc1.w", L.fc1w);
+            rc = rc ? rc : pack(p + "fc2.w", L.fc2w);
+        }
+        rc = rc ? rc : pack("head.w", h->head_w);
+        if (rc) return rc;
     }
     h->n_staged = 0;
     HIP_OK(h, hipDeviceSynchronize());
@@ -967,21 +1026,31 @@ int gitcap_text_forward(gitcap_t* h, const int64_t* ids, int ld_ids, int rows, i
                         (hipStream_t)stream);
 }
 
+// token steps 0 .. max_len-1 of `rows` text rows (the image K/V of their clips at h->kv_img), ids at ids_out (row pitch ld)
+static int greedy_rows(gitcap* h, int rows, int max_len, int64_t* ids_out, int ld, hipStream_t s) {
+    const bool chain = text_chain_ok(h, rows, 1);
+    bool have_rows = false;                                  // the previous step's arg-max launch embedded this step's input rows
+    for (int t = 0; t < max_len; ++t) {
+        // forward on the sequence so far, argmax of the last position, append (model.py:173-182)
+        const bool next = chain && t + 1 < max_len && t + 1 < h->c.max_text_pos;
+        const int rc = text_forward(h, ids_out + t, ld, rows, 1, t, 1, nullptr, 0, ids_out + t + 1, ld, h->sep_cnt, t, s, have_rows, next);
+        if (rc) return rc;
+        have_rows = next;
+    }
+    return 0;
+}
+
+// (Round 4 ran a synchronous call's loop as two / three / four part-batch loops side by side on the decode streams --
+// clips are independent, every kernel is batch invariant, the captions were bitwise the same: 16 clips 323-325 / 580 / 600 us
+// per token step against 302 for one loop (profiles/r04_sync_call_split_token_loop.txt).  Chains of ~6 us launches on
+// different streams do not overlap each other the way one chain overlaps an image pass.  Removed.)
 static int greedy_text_loop(gitcap* h, int B, int max_len, int stop, int64_t* ids_out, int32_t* steps_out, hipStream_t s) {
     const int ld = max_len + 1;
     int rc;
     // CLS start tokens [B,1] (model.py:171)
     HIP_OK(h, launch_fill_i64(ids_out, ld, B, h->c.cls_token_id, s));
     HIP_OK(h, hipMemsetAsync(h->sep_cnt, 0, ((size_t)h->Tmax + 1) * 4, s));
-    const bool chain = text_chain_ok(h, B, 1);
-    bool have_rows = false;                                  // the previous step's arg-max launch embedded this step's input rows
-    for (int t = 0; t < max_len; ++t) {
-        // forward on the sequence so far, argmax of the last position, append (model.py:173-182)
-        const bool next = chain && t + 1 < max_len && t + 1 < h->c.max_text_pos;
-        rc = text_forward(h, ids_out + t, ld, B, 1, t, 1, nullptr, 0, ids_out + t + 1, ld, h->sep_cnt, t, s, have_rows, next);
-        if (rc) return rc;
-        have_rows = next;
-    }
+    if ((rc = greedy_rows(h, B, max_len, ids_out, ld, s))) return rc;
     if (steps_out) HIP_OK(h, launch_finish_steps(h->sep_cnt, B, max_len, stop, steps_out, s));
     return 0;
 }
@@ -1228,7 +1297,9 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
 // check that results do not depend on them.  key 0: GEMM + LayerNorm epilogue on/off, 1: one/two-row prologue on/off,
 // 2: 256-tile threshold (GITCAP_GEMM_SMALL_TILES), 3: 128-tile threshold (GITCAP_GEMM_TINY_TILES), 4: 224-row tiles on/off,
 // 5: greedy loop chains token steps (the arg-max launch embeds the next step's input rows) on/off,
-// 6: polls a fused GEMM + LayerNorm tile waits for its siblings before it gives up (0 = default; 1 forces the fail-soft path).
+// 6: polls a fused GEMM + LayerNorm tile waits for its siblings before it gives up (0 = default; 1 forces the fail-soft path),
+// 7: text rows' FC1 -> GELU -> FC2 as one launch over hidden slices (ffn_txt.hip) on/off,
+// 8: gitcap_finalize_weights makes fragment-major copies of the text-path weights on/off (takes effect at the next finalize).
 // Returns the old value.
 int gitcap_dbg_config(int key, int value) {
     int old = -1;
@@ -1240,6 +1311,8 @@ int gitcap_dbg_config(int key, int value) {
         case 4: old = g_tile224.exchange(value != 0); break;
         case 5: old = g_chain_steps.exchange(value != 0); break;
         case 6: old = (int)g_ln_spin_limit.exchange((unsigned)(value > 0 ? value : 0)); break;
+        case 7: old = g_ffn_fuse.exchange(value != 0); break;
+        case 8: old = g_wpack.exchange(value != 0); break;
         default: return GITCAP_ERR_ARG;
     }
     return old;

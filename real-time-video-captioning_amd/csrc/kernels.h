@@ -75,6 +75,9 @@ struct SkinnyArgs {
         const float *g, *b; float eps;     // LayerNorm
         float* xf;                         // [M][K]
     } ln;
+    // optional fragment-major copy of W (launch_pack_frags: [tile][k32][lane][8]); when set the kernels read it instead of W
+    const void* Wpk;
+    int ksplit;                            // splitk: number of K slabs (0: skinny_ksplit(K))
 };
 extern std::atomic<bool> g_row_prologue;                                 // gitcap.hip: GITCAP_NO_ROW_PROLOGUE / gitcap_dbg_config(1, .)
 bool skinny_row_prologue_ok(int M, int K, bool fp8);         // shapes the row-prologue form is instantiated for
@@ -86,6 +89,24 @@ hipError_t launch_skinny_splitk(const SkinnyArgs& a, hipStream_t s);
 hipError_t launch_ln_reduce(const float* slabs, int nslab, const float* bias, const float* resid,
                             const float* gamma, const float* beta, float eps, int M, int D,
                             float* xf, bf16_t* xb, hipStream_t s);
+// fragment-major copy of a GEMM weight [rows16][K] (bf16: elem_bytes 2, e4m3 codes: 1) for the weight-streaming text kernels
+hipError_t launch_pack_frags(const void* src, void* dst, int rows16, int K, int elem_bytes, hipStream_t s);
+
+// ---- fused FC1 -> GELU -> FC2 of the text rows over hidden slices (ffn_txt.hip) -----------------------------------------
+// Workgroup s owns hidden units 64 s .. 64 s + 63: h = GELU(X W1_s^T + b1_s) rounded to bf16 (exactly the FC1 launch's
+// output), then its split-K share of FC2, slab[s][m][:] = h W2[:, slice]^T (fp32).  The slabs are summed by
+// launch_ln_reduce / the row prologue (nslab = F / 64).  Bitwise equal to launch_skinny (FC1 + GELU) followed by
+// launch_skinny_splitk with ksplit = F / 64.
+struct FfnTxtArgs {
+    const bf16_t* X; int ldx;                   // [M][D] bf16
+    const void *W1pk, *W2pk;                    // fragment-major FC1 [F][D] / FC2 [D][F]: bf16, or e4m3 codes when w1scale != nullptr
+    const float *w1scale, *w2scale;             // nullable: per-row power-of-two scales of e4m3 weights ([F] / [D])
+    const float* b1;                            // [F]
+    int M, D, F;
+    float* slabs;                               // [F / 64][M][D]
+};
+bool ffn_txt_ok(int D, int F);
+hipError_t launch_ffn_txt(const FfnTxtArgs& a, hipStream_t s);
 // out[r*ld_out] = index of the max over the per-tile partials of row r*row_stride + row_off.
 // emb (nullable; greedy loop, one position per row): the kernel goes on to embed the token it just chose at text position
 // emb->position -- word + position embedding -> LayerNorm -> xf / xb row r (rowln.h: the code of launch_embed_text) -- so
@@ -109,6 +130,7 @@ struct TxtBlockArgs {
     const bf16_t* kv_txt;                       // [R][Tmax][3D] this layer (q | k | v of the text rows)
     int rows, beams, t0, T, Tmax, S_img, H, D;
     const void* aow;                            // output dense [D][D]: bf16, or e4m3 bytes when aoscale != nullptr
+    const void* aowpk;                          // nullable (bf16 only): its fragment-major copy (launch_pack_frags)
     const float* aoscale;                       // nullable: [D] per-row power-of-two scale of e4m3 weights
     const float *aob, *g1, *b1;                 // its bias; LayerNorm of the sub-layer
     const float* xin;                           // [M][D] the sub-layer's input (residual)
@@ -117,7 +139,6 @@ struct TxtBlockArgs {
     unsigned* cnt;                              // [M] arrival tickets (zero between launches)
     float* xs; bf16_t* xsb;                     // out: x1 [M][D] fp32 and bf16 (xs may alias xin)
     int Mh;                                     // set by the launcher
-    int hm;                                     // experiment switch (txtblock.hip)
     int nt_kv;                                  // 1: the K/V rows are streamed with non-temporal loads (they do not fit the caches anyway)
 };
 bool txt_block_ok(int D);

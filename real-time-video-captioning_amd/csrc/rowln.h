@@ -34,29 +34,29 @@ __device__ __forceinline__ void row_layernorm(f32x4 (&v)[NV], const float s, con
     }
 }
 
-// v = sum_k slab[k][m] (fixed order) + bias + resid[m]; returns the lane-sum
+// t = the fixed-order sum of slabs k0 .. k0+7 of row m (missing slabs count as zero): all 8 x NV vectors are requested
+// before the first add (no serial latency chain)
 template <int NV>
-__device__ __forceinline__ float row_load_reduce(f32x4 (&v)[NV], const float* __restrict__ slabs, const int nslab,
-                                                 const float* __restrict__ bias, const float* __restrict__ resid,
-                                                 const int M, const int D, const int m, const int lane) {
+__device__ __forceinline__ void row_slab_tree(f32x4 (&t)[NV], const float* __restrict__ slabs, const int nslab, const int k0,
+                                              const int M, const int D, const int m, const int lane) {
+    f32x4 p[8][NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // 8 slabs x NV vectors are requested before the first add (no serial latency chain); the
-    // summation order is fixed, so the result does not depend on launch geometry or timing
-    for (int k0 = 0; k0 < nslab; k0 += 8) {
-        f32x4 p[8][NV];
+    for (int k = 0; k < 8; ++k)
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int i = 0; i < NV; ++i) {
+            const int c = i * 256 + lane * 4;
+            p[k][i] = (k0 + k < nslab && c < D) ? *(const f32x4*)(slabs + ((size_t)(k0 + k) * M + m) * D + c)
+                                                : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int c = i * 256 + lane * 4;
-                p[k][i] = (k0 + k < nslab && c < D) ? *(const f32x4*)(slabs + ((size_t)(k0 + k) * M + m) * D + c)
-                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-        for (int i = 0; i < NV; ++i)
-            v[i] += ((p[0][i] + p[1][i]) + (p[2][i] + p[3][i])) + ((p[4][i] + p[5][i]) + (p[6][i] + p[7][i]));
-    }
+    for (int i = 0; i < NV; ++i)
+        t[i] = ((p[0][i] + p[1][i]) + (p[2][i] + p[3][i])) + ((p[4][i] + p[5][i]) + (p[6][i] + p[7][i]));
+}
+
+// v += bias + resid[m]; returns the lane-sum
+template <int NV>
+__device__ __forceinline__ float row_add_bias_resid(f32x4 (&v)[NV], const float* __restrict__ bias, const float* __restrict__ resid,
+                                                    const int D, const int m, const int lane) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -67,6 +67,33 @@ __device__ __forceinline__ float row_load_reduce(f32x4 (&v)[NV], const float* __
         }
     }
     return s;
+}
+
+// v = sum_k slab[k][m] + bias + resid[m]; returns the lane-sum.  THE summation order of the text rows' split-K reduce:
+// groups of 8 slabs by the tree above, the groups added in ascending order -- whoever computes it (one wave here; one wave
+// per group in ln_reduce_kernel) gets the same bits, independent of launch geometry and timing.
+template <int NV>
+__device__ __forceinline__ float row_load_reduce(f32x4 (&v)[NV], const float* __restrict__ slabs, const int nslab,
+                                                 const float* __restrict__ bias, const float* __restrict__ resid,
+                                                 const int M, const int D, const int m, const int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int k0 = 0;
+    // two groups per round trip while there are that many (48 slabs: 3 round trips instead of 6); the adds keep their order
+    for (; k0 + 8 < nslab; k0 += 16) {
+        f32x4 ta[NV], tb[NV];
+        row_slab_tree<NV>(ta, slabs, nslab, k0, M, D, m, lane);
+        row_slab_tree<NV>(tb, slabs, nslab, k0 + 8, M, D, m, lane);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { v[i] += ta[i]; v[i] += tb[i]; }
+    }
+    for (; k0 < nslab; k0 += 8) {
+        f32x4 t[NV];
+        row_slab_tree<NV>(t, slabs, nslab, k0, M, D, m, lane);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] += t[i];
+    }
+    return row_add_bias_resid<NV>(v, bias, resid, D, m, lane);
 }
 
 // v = word[tok] + pos[position]; returns the lane-sum

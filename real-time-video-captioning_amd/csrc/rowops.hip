@@ -218,18 +218,58 @@ __global__ __launch_bounds__(256) void embed_text_kernel(const int64_t* __restri
     row_store<NV>(v, lane, D, xf + (size_t)m * D, xb + (size_t)m * D);
 }
 
-// ---- split-K reduce + bias + residual + LayerNorm (text rows): one wave per row (rowln.h) -------
+// ---- split-K reduce + bias + residual + LayerNorm (text rows) (rowln.h) ---------------------------------------------
+// One workgroup per row, one wave per group of 8 slabs: every wave sums its group (row_slab_tree), wave 0 adds the group
+// sums in ascending order, then bias + residual, and normalises the row.  With up to 8 slabs that is one wave, the kernel of
+// rounds 1-3; the fused FC1 -> GELU -> FC2 launch of round 4 (ffn_txt.hip) leaves dec_ffn / 64 = 48 slabs, 147 KB per
+// row: six waves fetch them side by side.  Same bits as row_load_reduce in one wave (the row prologue of skinny.hip).
 template <int NV>
-__global__ __launch_bounds__(64) void ln_reduce_kernel(const float* __restrict__ slabs, int nslab,
-                                                       const float* __restrict__ bias, const float* __restrict__ resid,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       float eps, int M, int D, float* __restrict__ xf,
-                                                       bf16_t* __restrict__ xb) {
-    const int lane = threadIdx.x, m = blockIdx.x;
+__global__ __launch_bounds__(512) void ln_reduce_kernel(const float* __restrict__ slabs, int nslab,
+                                                        const float* __restrict__ bias, const float* __restrict__ resid,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, int M, int D, float* __restrict__ xf,
+                                                        bf16_t* __restrict__ xb) {
+    __shared__ __attribute__((aligned(16))) float part[7][NV * 256];           // group sums of waves 1..7
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, m = blockIdx.x;
+    const int ngroups = (nslab + 7) >> 3;
     f32x4 v[NV];
-    const float s = row_load_reduce<NV>(v, slabs, nslab, bias, resid, M, D, m, lane);
+    row_slab_tree<NV>(v, slabs, nslab, g * 8, M, D, m, lane);
+    if (ngroups > 1) {
+        if (g > 0) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) *(f32x4*)(&part[g - 1][i * 256 + lane * 4]) = v[i];
+        }
+        __syncthreads();
+        if (g > 0) return;
+        for (int j = 1; j < ngroups; ++j)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] += *(const f32x4*)(&part[j - 1][i * 256 + lane * 4]);
+    }
+    // (0 + t0) + t1 + ... of row_load_reduce: 0 + t0 == t0 exactly
+    const float s = row_add_bias_resid<NV>(v, bias, resid, D, m, lane);
     row_layernorm<NV>(v, s, lane, D, eps, gamma, beta);
     row_store<NV>(v, lane, D, xf + (size_t)m * D, xb + (size_t)m * D);
+}
+
+// ---- fragment-major copy of a GEMM weight for the weight-streaming text kernels ------------------------------------------
+// src [Npad16][K] (ESZ-byte elements: bf16, or e4m3 codes) -> dst [tile = n / 16][k32 = k / 32][lane][8 elements] with
+// lane = n % 16 + 16 * ((k % 32) / 8): the MFMA operand a lane of skinny.hip / txtblock.hip / ffn_txt.hip loads for k-step
+// k32 of tile n / 16 is 16 (8) contiguous bytes, a wave instruction reads 1 KiB (512 B) contiguous and a tile's fragments
+// are one contiguous run.  Measured (tools/probe/pull_probe.hip): a CU pulls 48 KiB per wave at 47 GB/s in the row-major
+// pattern (16 segments of 64 B per instruction) and at 170 GB/s (71 from cold caches) from this layout.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_frags_kernel(const T* __restrict__ src, T* __restrict__ dst, int K, int64_t total8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;            // one 8-element fragment piece per thread
+    if (i >= total8) return;
+    const int lane = (int)(i & 63);
+    const int64_t tk = i >> 6;
+    const int K32 = K >> 5;
+    const int64_t tile = tk / K32;
+    const int k32 = (int)(tk - tile * K32);
+    const T* sp = src + ((size_t)tile * 16 + (lane & 15)) * K + k32 * 32 + (lane >> 4) * 8;
+    T* dp = dst + (size_t)i * 8;
+    if (sizeof(T) == 2) *(uint4*)dp = *(const uint4*)sp;
+    else *(uint2*)dp = *(const uint2*)sp;
 }
 
 // ---- final arg-max over the per-tile partials written by the vocabulary-head kernel ------------
@@ -572,12 +612,22 @@ hipError_t launch_layernorm(const LnArgs& a, hipStream_t s) {
 
 hipError_t launch_ln_reduce(const float* slabs, int nslab, const float* bias, const float* resid, const float* gamma,
                             const float* beta, float eps, int M, int D, float* xf, bf16_t* xb, hipStream_t s) {
-    if (M <= 0 || D % 4 || D > 1024 || nslab < 1) return hipErrorInvalidValue;
+    if (M <= 0 || D % 4 || D > 1024 || nslab < 1 || nslab > 64) return hipErrorInvalidValue;
     const int nv = (D + 255) / 256;
-    if (nv == 1) hipLaunchKernelGGL(ln_reduce_kernel<1>, dim3(M), dim3(64), 0, s, slabs, nslab, bias, resid, gamma, beta, eps, M, D, xf, xb);
-    else if (nv == 2) hipLaunchKernelGGL(ln_reduce_kernel<2>, dim3(M), dim3(64), 0, s, slabs, nslab, bias, resid, gamma, beta, eps, M, D, xf, xb);
-    else if (nv == 3) hipLaunchKernelGGL(ln_reduce_kernel<3>, dim3(M), dim3(64), 0, s, slabs, nslab, bias, resid, gamma, beta, eps, M, D, xf, xb);
-    else hipLaunchKernelGGL(ln_reduce_kernel<4>, dim3(M), dim3(64), 0, s, slabs, nslab, bias, resid, gamma, beta, eps, M, D, xf, xb);
+    const dim3 block(64 * ((nslab + 7) / 8));
+    if (nv == 1) hipLaunchKernelGGL(ln_reduce_kernel<1>, dim3(M), block, 0, s, slabs, nslab, bias, resid, gamma, beta, eps, M, D, xf, xb);
+    else if (nv == 2) hipLaunchKernelGGL(ln_reduce_kernel<2>, dim3(M), block, 0, s, slabs, nslab, bias, resid, gamma, beta, eps, M, D, xf, xb);
+    else if (nv == 3) hipLaunchKernelGGL(ln_reduce_kernel<3>, dim3(M), block, 0, s, slabs, nslab, bias, resid, gamma, beta, eps, M, D, xf, xb);
+    else hipLaunchKernelGGL(ln_reduce_kernel<4>, dim3(M), block, 0, s, slabs, nslab, bias, resid, gamma, beta, eps, M, D, xf, xb);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_frags(const void* src, void* dst, int rows16, int K, int elem_bytes, hipStream_t s) {
+    if (rows16 <= 0 || rows16 % 16 || K % 32 || (elem_bytes != 1 && elem_bytes != 2)) return hipErrorInvalidValue;
+    const int64_t total8 = (int64_t)rows16 * K / 8;
+    const dim3 grid((unsigned)((total8 + 255) / 256));
+    if (elem_bytes == 2) hipLaunchKernelGGL(pack_frags_kernel<unsigned short>, grid, dim3(256), 0, s, (const unsigned short*)src, (unsigned short*)dst, K, total8);
+    else hipLaunchKernelGGL(pack_frags_kernel<unsigned char>, grid, dim3(256), 0, s, (const unsigned char*)src, (unsigned char*)dst, K, total8);
     return hipGetLastError();
 }
 

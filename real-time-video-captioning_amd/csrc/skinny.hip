@@ -30,8 +30,28 @@ namespace {
 
 // weight fragments of one 16-row tile, K32 k-steps.  FP8: e4m3 bytes (8 per lane and k-step, half the stream),
 // expanded in registers to bf16 times the row's power-of-two scale (exact: the bf16-stored weight bit for bit).
+// Wpk != nullptr: the fragment-major copy (launch_pack_frags): fragment k of this wave = 1 KiB (512 B) contiguous per
+// wave instruction, `kofs` / 32 k-steps into tile `row` / 16 -- 3-4 x the per-CU pull rate of the row-major pattern.
 template <int K32, bool FP8>
-__device__ __forceinline__ void load_wfrags(const void* W, const float* wscale, size_t row, int K, int kofs, bf16x8 (&wf)[K32]) {
+__device__ __forceinline__ void load_wfrags(const void* W, const void* Wpk, const float* wscale, size_t row, int K, int kofs, bf16x8 (&wf)[K32]) {
+    if (Wpk) {
+        const int lane = threadIdx.x & 63;
+        const size_t f0 = ((row >> 4) * (size_t)(K >> 5) + (size_t)(kofs >> 5)) * 64 + lane;      // fragment index of k-step 0
+        if (FP8) {
+            const uint2* wp = (const uint2*)Wpk + f0;
+            const float sc = wscale[row];
+            uint2 raw[K32];
+#pragma unroll
+            for (int k = 0; k < K32; ++k) raw[k] = wp[(size_t)k * 64];
+#pragma unroll
+            for (int k = 0; k < K32; ++k) wf[k] = fp8x8_to_bf16x8(raw[k], sc);
+        } else {
+            const bf16x8* wp = (const bf16x8*)Wpk + f0;
+#pragma unroll
+            for (int k = 0; k < K32; ++k) wf[k] = wp[(size_t)k * 64];
+        }
+        return;
+    }
     if (FP8) {
         const unsigned char* wp = (const unsigned char*)W + row * K + kofs;
         const float sc = wscale[row];
@@ -53,7 +73,7 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
     const int frow = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * 16;
     bf16x8 wf[K32];
-    load_wfrags<K32, FP8>(a.W, a.wscale, (size_t)(n0 + frow), a.K, fq * 8, wf);
+    load_wfrags<K32, FP8>(a.W, a.Wpk, a.wscale, (size_t)(n0 + frow), a.K, fq * 8, wf);
     __shared__ __attribute__((aligned(16))) bf16_t xrow[LNR ? 2 : 1][LNR ? K32 * 32 : 8];
     if (LNR) {
         constexpr int NV = (K32 * 32 + 255) / 256;
@@ -158,7 +178,7 @@ __global__ __launch_bounds__(64) void skinny_splitk_kernel(SkinnyArgs a) {
     const int n0 = blockIdx.x * 16, ks = blockIdx.y;
     const int kbeg = ks * K32 * 32;
     bf16x8 wf[K32];
-    load_wfrags<K32, FP8>(a.W, a.wscale, (size_t)(n0 + frow), a.K, kbeg + fq * 8, wf);
+    load_wfrags<K32, FP8>(a.W, a.Wpk, a.wscale, (size_t)(n0 + frow), a.K, kbeg + fq * 8, wf);
     const int n = n0 + fq * 4;
     float* slab = (float*)a.out + (size_t)ks * a.M * a.ldo;
     const int mtiles = (a.M + 15) >> 4;
@@ -249,8 +269,8 @@ int skinny_ksplit(int K) {
 }
 
 hipError_t launch_skinny_splitk(const SkinnyArgs& a, hipStream_t s) {
-    const int ks = skinny_ksplit(a.K);
-    if (!ks || a.M <= 0 || a.N % 16) return hipErrorInvalidValue;
+    const int ks = a.ksplit > 0 ? a.ksplit : skinny_ksplit(a.K);
+    if (!ks || a.M <= 0 || a.N % 16 || a.K % (ks * 32)) return hipErrorInvalidValue;
     dim3 grid(a.N / 16, ks);
     if (a.wscale) {
         switch (a.K / ks / 32) {

@@ -121,11 +121,10 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
 
     const int Lk = a.S_img + tq + 1;
     const int sub = lane & 7, kk = lane >> 3;
-    // EXPERIMENT (GITCAP_TXT_HM=1, timing only -- the data read is not the K/V): image keys addressed as if the cache were
-    // head-major [clip][head][key][K 64 | V 64], i.e. one contiguous 256-B record per key and a contiguous stream per unit
-    const int kstride = a.hm ? 128 : ld, voff = a.hm ? 64 : D;
-    const bf16_t* img = a.hm ? a.kv_img + ((size_t)(clip * H + head) * a.S_img) * 128 + sub * 8
-                             : a.kv_img + (size_t)clip * a.S_img * ld + D + head * 64 + sub * 8;
+    // (Round 4 timed a head-major image K/V cache -- one contiguous 256-B record per key and head, a contiguous stream per
+    // unit -- by addressing this buffer that way: 301 vs 307 us per token step at 16 clips, 209 vs 211 at one
+    // (profiles/r04_text_attention_head_major_kv_timing.txt).  Not worth a second GEMM epilogue and attention read path.)
+    const bf16_t* img = a.kv_img + (size_t)clip * a.S_img * ld + D + head * 64 + sub * 8;
     const bf16_t* txt = a.kv_txt + (size_t)r * a.Tmax * ld + D + head * 64 + sub * 8;
     char* mypre = kvpre + wid * 8192;
     // group 0 of this wave (keys 32 wid .. +31) -> LDS, lane-linear (lane = kk*8 + sub, one 1-KiB piece per 8 keys)
@@ -134,15 +133,13 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
         for (int u = 0; u < 4; ++u) {
             int key = wid * 32 + u * 8 + kk;
             key = key < Lk ? key : 0;
-            const bool isimg = key < a.S_img;
-            const bf16_t* kp = isimg ? img + (size_t)key * kstride : txt + (size_t)(key - a.S_img) * ld;
-            const bf16_t* vp = kp + (isimg ? voff : D);
+            const bf16_t* kp = key < a.S_img ? img + (size_t)key * ld : txt + (size_t)(key - a.S_img) * ld;
             if (a.nt_kv) {
                 __builtin_amdgcn_global_load_lds(GLB_PTR(kp), LDS_PTR(mypre + u * 1024), 16, 0, 2);
-                __builtin_amdgcn_global_load_lds(GLB_PTR(vp), LDS_PTR(mypre + 4096 + u * 1024), 16, 0, 2);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(kp + D), LDS_PTR(mypre + 4096 + u * 1024), 16, 0, 2);
             } else {
                 __builtin_amdgcn_global_load_lds(GLB_PTR(kp), LDS_PTR(mypre + u * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(GLB_PTR(vp), LDS_PTR(mypre + 4096 + u * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(kp + D), LDS_PTR(mypre + 4096 + u * 1024), 16, 0, 0);
             }
         }
     };
@@ -169,15 +166,13 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
             int key = g0 + u * 8 + kk;
             valid[u] = key < Lk;
             key = valid[u] ? key : 0;
-            const bool isimg = key < a.S_img;
-            const bf16_t* kp = isimg ? img + (size_t)key * kstride : txt + (size_t)(key - a.S_img) * ld;
-            const bf16_t* vp = kp + (isimg ? voff : D);
+            const bf16_t* kp = key < a.S_img ? img + (size_t)key * ld : txt + (size_t)(key - a.S_img) * ld;
             if (a.nt_kv) {      // read once per launch and too large to stay cached: do not displace what the GEMMs re-read
                 kf[u] = __builtin_nontemporal_load((const bf16x8*)kp);
-                vf[u] = __builtin_nontemporal_load((const bf16x8*)vp);
+                vf[u] = __builtin_nontemporal_load((const bf16x8*)(kp + D));
             } else {
                 kf[u] = *(const bf16x8*)kp;
-                vf[u] = *(const bf16x8*)vp;
+                vf[u] = *(const bf16x8*)(kp + D);
             }
         }
     };
@@ -223,6 +218,10 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         __builtin_amdgcn_global_load_lds(GLB_PTR(wp + (q >> 1) * 32 + (q & 1) * 4), LDS_PTR(mypre + (4 * i + q) * 256), 4, 0, 0);
+                } else if (a.aowpk) {   // bf16, fragment-major copy: k-steps 2 head, 2 head + 1 of tile t = 2 KiB contiguous
+                    const bf16_t* wp = (const bf16_t*)a.aowpk + (((size_t)t * K32 + head * 2) * 64 + lane) * 8;
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(wp), LDS_PTR(mypre + (2 * i) * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(wp + 512), LDS_PTR(mypre + (2 * i + 1) * 1024), 16, 0, 0);
                 } else {        // bf16: [tile][k-half][lane] 16 bytes
                     const bf16_t* wp = (const bf16_t*)a.aow + (size_t)(t * 16 + frow) * D + head * 64 + fq * 8;
                     __builtin_amdgcn_global_load_lds(GLB_PTR(wp), LDS_PTR(mypre + (2 * i) * 1024), 16, 0, 0);
@@ -369,8 +368,6 @@ hipError_t launch_txt_block(const TxtBlockArgs& a_in, hipStream_t s) {
     TxtBlockArgs a = a_in;
     static const int nt = getenv("GITCAP_TXT_NT") ? atoi(getenv("GITCAP_TXT_NT")) : -1;    // A/B switch: 0 never, 1 always
     if (nt >= 0) a.nt_kv = nt;
-    static const int hm = getenv("GITCAP_TXT_HM") ? atoi(getenv("GITCAP_TXT_HM")) : 0;           // experiment: see the kernel
-    a.hm = hm;
     const int M = a.rows * a.T;
     if (M <= 0 || a.H * 64 != a.D || a.beams <= 0 || !a.xin) return hipErrorInvalidValue;
     // first "half" of the rows for heads 8..11 (H == 12 mapping): whole clips (all beams of a clip stay together)

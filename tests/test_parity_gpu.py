@@ -184,7 +184,7 @@ def test_results_do_not_depend_on_speed_switches(captioner_cls):
         return vis.clone(), ids.clone(), m.forward_decoder(ids[:, :-1], vis).clone()
     base8, base1 = run(8), run(1)
     assert torch.equal(base1[1], base8[1][:1]) and torch.equal(base1[0], base8[0][:1])
-    settings = [(0, 0), (1, 0), (2, 1 << 30), (3, 0), (3, 1 << 30), (2, 1), (4, 0), (5, 0)]   # (key, value); (2, 1): 256-tile kernels even for one clip; (4, 0): no 224-row tiles; (5, 0): every token step embeds its own input rows
+    settings = [(0, 0), (1, 0), (2, 1 << 30), (3, 0), (3, 1 << 30), (2, 1), (4, 0), (5, 0), (7, 0)]   # (key, value); (2, 1): 256-tile kernels even for one clip; (4, 0): no 224-row tiles; (5, 0): every token step embeds its own input rows; (7, 0): FC1 and FC2 of the text rows as two launches
     for key, value in settings:
         old = lib.gitcap_dbg_config(key, value)
         assert old >= 0
@@ -195,6 +195,17 @@ def test_results_do_not_depend_on_speed_switches(captioner_cls):
                     assert torch.equal(a, b), (key, value, n)
         finally:
             lib.gitcap_dbg_config(key, old)
+    # key 8 acts when the weights are finalised: a handle whose text kernels read the row-major weights (no fragment-major
+    # copies; its FFN then runs as two launches) gives the same bits
+    old = lib.gitcap_dbg_config(8, 0)
+    try:
+        m2 = captioner_cls(cfg, w, max_batch=8, max_frames=6, max_text_len=12)
+    finally:
+        lib.gitcap_dbg_config(8, old)
+    for base, n in ((base8, 8), (base1, 1)):
+        _, vis = m2.forward_image_enc(fr[:n])
+        ids = m2.greedy_decode(fr[:n], max_len=12, stop="never")
+        assert torch.equal(ids, base[1]) and torch.equal(m2.forward_decoder(ids[:, :-1], vis), base[2]), n
     assert lib.gitcap_dbg_config(99, 0) < 0
 
 
