@@ -290,6 +290,10 @@ int gitcap_student_forward_decoder(gitcap_student_t* h, const int64_t* ids, int 
  * generated tokens under the stop rule (enum gitcap_stop; GITCAP_STOP_ALL_SEP = model.py:184). */
 int gitcap_student_greedy(gitcap_student_t* h, const float* memory, int B, int max_len, int stop,
                           int64_t* ids_out, int32_t* steps_out, void* stream);
+/* StudentCandidateV1.beam_search (src/models/model.py:189-318) on the device, KV-cached, no host round trip: memory [B][F][D] fp32
+ * (device), k beams (rows b * k + i; B * k <= max_rows, k <= 16), no end-of-sequence handling (as the reference);
+ * ids_out [B][max_len] = the best beam of every clip, CLS first (model.py:317). */
+int gitcap_student_beam_search(gitcap_student_t* h, const float* memory, int B, int k, int max_len, int64_t* ids_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,43 @@ hipError_t launch_student_embed(const int64_t* ids, int ld_ids, int rows, int T,
     return hipGetLastError();
 }
 
+// ---- device-resident beam search of the student (model.py:189-318): bookkeeping kernels ----------------------------------
+// dst[(b * k + i)][:] = src[b][:]  (the k beams of a clip share its memory rows)
+__global__ __launch_bounds__(256) void repeat_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int k, int n4) {
+    const int r = blockIdx.y;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256)
+        ((f32x4*)dst)[(size_t)r * n4 + i] = ((const f32x4*)src)[(size_t)(r / k) * n4 + i];
+}
+// beam scores before the first step: only beam 0 of every clip is live (all k rows hold the same prefix [CLS])
+__global__ void beam_scores_init_kernel(float* scores, int rows, int k) {
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r < rows) scores[r] = (r % k == 0) ? 0.f : -1e9f;
+}
+// one step of model.py:252-287: candidate j of clip b (sorted best first by beam_topk; flat index = beam * V + token) becomes
+// row b * k + j: its prefix is the prefix of row b * k + beam, its new token the candidate's, its score the candidate's
+__global__ __launch_bounds__(64) void student_beam_step_kernel(const float* __restrict__ cand_scores, const int* __restrict__ cand_idx,
+                                                               const int64_t* __restrict__ ids_cur, int64_t* __restrict__ ids_next,
+                                                               float* __restrict__ scores, int32_t* __restrict__ src_rows,
+                                                               int k, int V, int t, int ld) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int j = 0; j < k; ++j) {
+        const int idx = cand_idx[b * k + j];
+        const int beam = idx / V, tok = idx - beam * V;
+        const int src = b * k + beam, dst = b * k + j;
+        for (int i = lane; i <= t; i += 64) ids_next[(size_t)dst * ld + i] = ids_cur[(size_t)src * ld + i];
+        if (lane == 0) {
+            ids_next[(size_t)dst * ld + t + 1] = tok;
+            scores[dst] = cand_scores[b * k + j];
+            src_rows[dst] = src;
+        }
+    }
+}
+// the best beam of every clip (row b * k: the candidates arrive sorted) -> out [B][max_len]
+__global__ void student_beam_finish_kernel(const int64_t* __restrict__ ids, int64_t* __restrict__ out, int k, int ld, int max_len) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < max_len; i += 64) out[(size_t)b * max_len + i] = ids[(size_t)b * k * ld + i];
+}
+
 struct gitcap_student {
     gitcap_student_config c;
     int device = 0;
@@ -122,6 +159,13 @@ struct gitcap_student {
     struct GreedyGraph { int B, max_len, stop; bool rows_pro; hipGraphExec_t exec; };
     std::vector<GreedyGraph> graphs;
     hipStream_t cap_stream = nullptr;   // capture only (the legacy default stream cannot be captured); replays run on the caller's stream
+    // device-resident beam search (gitcap_student_beam_search), allocated on first use
+    struct BeamWs {
+        float *memrep = nullptr, *scores = nullptr, *cand_scores = nullptr, *logits = nullptr;
+        int* cand_idx = nullptr; int32_t* src_rows = nullptr;
+        int64_t *ids0 = nullptr, *ids1 = nullptr;
+        bf16_t* kvs2 = nullptr; char* topk_scratch = nullptr;
+    } bw;
     // resolved weights
     const float *embed = nullptr, *pe = nullptr, *head_b = nullptr;
     const bf16_t* head_w = nullptr;
@@ -473,6 +517,68 @@ int gitcap_student_greedy(gitcap_student_t* h, const float* memory, int B, int m
     }
     S_HIP_OK(h, hipMemcpyAsync(ids_out, h->g_ids, (size_t)B * ld * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     if (steps_out) S_HIP_OK(h, hipMemcpyAsync(steps_out, h->g_steps, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// StudentCandidateV1.beam_search (model.py:189-318) on the device with the exact KV cache: k beams per clip as rows
+// b * k + i, no end-of-sequence handling (as the reference), no host round trip.  The reference lets every beam propose its
+// top k and keeps the k best of the k * k candidates; the k best of ALL beams x vocabulary candidates are the same set (a
+// candidate among the global k best is among its own beam's k best), which is what beam_topk ranks (log_softmax + beam
+// score, best first, ties to the smaller beam-major index).  Before the first step only beam 0 is live (score 0, the others
+// -1e9), so the k rows start as the top k of the single prefix [CLS] (model.py:221-227).  After every step the self-attention
+// K/V rows follow their beams (gather into the second cache buffer) and so do the id rows the PAD-key mask reads.
+int gitcap_student_beam_search(gitcap_student_t* h, const float* memory, int B, int k, int max_len, int64_t* ids_out, void* stream) {
+    if (!h) return sfail(h, GITCAP_ERR_ARG, "student_beam_search: null handle");
+    if (!memory || !ids_out || B <= 0 || k <= 0 || max_len < 2) return sfail(h, GITCAP_ERR_ARG, "student_beam_search: bad arguments");
+    if (k > 16) return sfail(h, GITCAP_ERR_ARG, "student_beam_search: at most 16 beams");
+    if ((int64_t)B * k > h->R) return sfail(h, GITCAP_ERR_ARG, "student_beam_search: B * k exceeds max_rows");
+    if (max_len > h->Tmax) return sfail(h, GITCAP_ERR_ARG, "student_beam_search: max_len exceeds max_text_len + 1");
+    S_GUARD(h);
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = B * k, D = h->D, V = h->V, ld = h->Tmax + 1;
+    int rc = 0;
+    gitcap_student::BeamWs& w = h->bw;
+    if (!w.memrep) {
+        const size_t R = h->R;
+        rc = rc ? rc : s_alloc(h, &w.memrep, R * h->F * D);
+        rc = rc ? rc : s_alloc(h, &w.scores, R);
+        rc = rc ? rc : s_alloc(h, &w.cand_scores, R);
+        rc = rc ? rc : s_alloc(h, &w.cand_idx, R);
+        rc = rc ? rc : s_alloc(h, &w.src_rows, R);
+        rc = rc ? rc : s_alloc(h, &w.ids0, R * (size_t)ld);
+        rc = rc ? rc : s_alloc(h, &w.ids1, R * (size_t)ld);
+        rc = rc ? rc : s_alloc(h, &w.logits, R * (size_t)V);
+        rc = rc ? rc : s_alloc(h, &w.kvs2, (size_t)h->L * h->R * h->Tmax * 3 * D);
+        rc = rc ? rc : s_alloc(h, &w.topk_scratch, beam_topk_scratch_bytes(h->R, 1, V, 16));     // rows x chunks, whatever the split into clips x beams
+        if (rc) { w = gitcap_student::BeamWs{}; return rc; }
+    }
+    hipLaunchKernelGGL(repeat_rows_kernel, dim3(4, rows), dim3(256), 0, s, memory, w.memrep, k, h->F * D / 4);
+    S_HIP_OK(h, hipGetLastError());
+    if ((rc = set_memory(h, w.memrep, rows, s))) return rc;
+    S_HIP_OK(h, launch_fill_i64(w.ids0, ld, rows, h->c.cls_token_id, s));
+    hipLaunchKernelGGL(beam_scores_init_kernel, dim3((rows + 63) / 64), dim3(64), 0, s, w.scores, rows, k);
+    S_HIP_OK(h, hipGetLastError());
+    int64_t *cur = w.ids0, *nxt = w.ids1;
+    bf16_t* const kvs_home = h->kvs;
+    const size_t kv_layer = (size_t)h->R * h->Tmax * 3 * D;
+    for (int t = 0; t + 1 < max_len && !rc; ++t) {                      // the token at position t is decoded, position t + 1 chosen
+        if (t > 0) {                                                    // rows continue beam src_rows[r]: positions 0 .. t-1, all layers
+            bf16_t* other = h->kvs == kvs_home ? w.kvs2 : kvs_home;
+            S_HIP_OK(h, launch_gather_txt_rows(h->kvs, other, w.src_rows, rows, t, h->Tmax, 3 * D, h->L, kv_layer, s));
+            h->kvs = other;
+        }
+        rc = text_forward(h, cur, ld, rows, t, 1, w.logits, nullptr, 0, nullptr, 0, s);
+        if (rc) break;
+        hipError_t e = launch_beam_topk(w.logits, V, w.scores, B, k, V, k, w.cand_scores, w.cand_idx, w.topk_scratch, s);
+        if (e != hipSuccess) { rc = sfail(h, GITCAP_ERR_HIP, std::string("student_beam_search: beam_topk: ") + hipGetErrorString(e)); break; }
+        hipLaunchKernelGGL(student_beam_step_kernel, dim3(B), dim3(64), 0, s, w.cand_scores, w.cand_idx, cur, nxt, w.scores, w.src_rows, k, V, t, ld);
+        if (hipGetLastError() != hipSuccess) { rc = sfail(h, GITCAP_ERR_HIP, "student_beam_search: beam step launch"); break; }
+        std::swap(cur, nxt);
+    }
+    h->kvs = kvs_home;                                                  // (the captured greedy graphs hold this pointer)
+    if (rc) return rc;
+    hipLaunchKernelGGL(student_beam_finish_kernel, dim3(B), dim3(64), 0, s, cur, ids_out, k, ld, max_len);
+    S_HIP_OK(h, hipGetLastError());
     return 0;
 }
 

@@ -57,6 +57,7 @@ SYMBOLS = {
     "gitcap_student_set_memory": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "gitcap_student_forward_decoder": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gitcap_student_greedy": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gitcap_student_beam_search": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

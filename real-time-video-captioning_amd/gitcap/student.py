@@ -213,8 +213,29 @@ class StudentCaptioner(nn.Module):
     @torch.no_grad()
     def beam_search(self, src: torch.Tensor, max_len: int = 10, k: int = 3) -> torch.Tensor:
         """model.py:189-318: k beams without end-of-sequence handling; returns the best beam [B, max_len].
-        The k beams of a clip are rows of one ``forward_decoder`` call (B*k <= max_batch); like the
-        reference, every step recomputes the whole prefix."""
+        Runs on the device with the exact KV cache and no host round trip (``gitcap_student_beam_search``): the k beams
+        of a clip are rows b*k+i (B*k <= max_batch), candidates are ranked by the beam top-k kernel, the cached K/V rows
+        follow their beams."""
+        out_dev = src.device
+        memory = self.forward_image_enc(src)[1] if src.dim() == 5 else src
+        mem = self._memory(memory)
+        B = mem.shape[0]
+        if B * k > self.max_batch:
+            raise ValueError(f"B*k={B * k} rows > max_batch={self.max_batch}")
+        if max_len - 1 > self.max_text_len:
+            raise ValueError(f"max_len={max_len} exceeds max_text_len+1={self.max_text_len + 1}")
+        if max_len < 2 or k < 1 or k > 16:
+            raise ValueError("beam_search needs max_len >= 2 and 1 <= k <= 16")
+        best = torch.empty((B, max_len), dtype=torch.int64, device=self._dev)
+        with torch.cuda.device(self._dev):
+            self._call("gitcap_student_beam_search", ctypes.c_void_p(mem.data_ptr()), B, k, max_len,
+                       ctypes.c_void_p(best.data_ptr()), self._stream())
+        return best.to(out_dev) if out_dev != best.device else best
+
+    @torch.no_grad()
+    def beam_search_host(self, src: torch.Tensor, max_len: int = 10, k: int = 3) -> torch.Tensor:
+        """The same search driven from the host the way the reference writes it (every step recomputes the whole prefix
+        through ``forward_decoder``, one host sync per step): the cross-check of ``beam_search`` in the tests."""
         out_dev = src.device
         memory = self.forward_image_enc(src)[1] if src.dim() == 5 else src
         mem = self._memory(memory)

@@ -237,6 +237,18 @@ def test_gpu_beam_search(golden_dir):
     assert (got == torch.from_numpy(g["beam_k3"])).float().mean().item() > 0.8
     with pytest.raises(ValueError):
         m.beam_search(make_memory(5, cfg.mem_tokens, cfg.d_model, 1), max_len=5, k=3)      # 15 rows > max_batch
+    # the device-resident search (KV-cached, candidates ranked and beams reordered on the GPU) against the same search
+    # driven from the host over full-prefix forward_decoder calls: the cache is exact (bitwise), so the same beams
+    for kk, ml in ((3, 9), (4, 6), (2, 12), (1, 5)):
+        assert torch.equal(m.beam_search(mem, max_len=ml, k=kk), m.beam_search_host(mem, max_len=ml, k=kk)), (kk, ml)
+    # and at the reference's model size (config.py:78-83), where a greedy call in between must still see its own cache
+    cfgb = student_base()
+    mb = _student(cfgb, student_synthetic_weights(cfgb, 0), max_batch=8, max_text_len=25)
+    memb = make_memory(2, cfgb.mem_tokens, cfgb.d_model, 5)
+    gr = mb.greedy_decode(memb, max_len=10, stop="never")
+    bs = mb.beam_search(memb, max_len=12, k=4)
+    assert torch.equal(bs, mb.beam_search_host(memb, max_len=12, k=4))
+    assert torch.equal(mb.greedy_decode(memb, max_len=10, stop="never"), gr)
 
 
 @pytest.mark.gpu
