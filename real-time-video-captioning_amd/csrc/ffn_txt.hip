@@ -77,6 +77,18 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
     float* slab = a.slabs + (size_t)s * a.M * D;
 
     const int mtiles = (a.M + 15) >> 4;
+    // 32 or more rows: the activation fragments of m-tile mt + 1 are requested before the MFMAs of m-tile mt, 8 k-steps at a
+    // time (the registers next to 192 of weight fragments)
+    constexpr int XC = K32 < 8 ? K32 : 8;
+    bf16x8 xnext[XC];
+    auto load_x = [&](int mt) {
+        int m = mt * 16 + frow;
+        m = m < a.M ? m : a.M - 1;
+        const bf16_t* xp = a.X + (size_t)m * a.ldx + fq * 8;
+#pragma unroll
+        for (int k = 0; k < XC; ++k) xnext[k] = *(const bf16x8*)(xp + k * 32);
+    };
+    load_x(0);
     for (int mt = 0; mt < mtiles; ++mt) {
         int m = mt * 16 + frow;
         const bool mvalid = m < a.M;
@@ -85,10 +97,13 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
         const bf16_t* xp = a.X + (size_t)m * a.ldx + fq * 8;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < K32; ++k) {
+        for (int k = 0; k < XC; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[k], xnext[k], acc, 0, 0, 0);
+#pragma unroll
+        for (int k = XC; k < K32; ++k) {
             const bf16x8 xf = *(const bf16x8*)(xp + k * 32);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[k], xf, acc, 0, 0, 0);
         }
+        if (mt + 1 < mtiles) load_x(mt + 1);
         uint2 hv;
         hv.x = pack_bf2(erf_gelu(acc[0] + bias[0]), erf_gelu(acc[1] + bias[1]));
         hv.y = pack_bf2(erf_gelu(acc[2] + bias[2]), erf_gelu(acc[3] + bias[3]));

@@ -1299,7 +1299,8 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
 // 5: greedy loop chains token steps (the arg-max launch embeds the next step's input rows) on/off,
 // 6: polls a fused GEMM + LayerNorm tile waits for its siblings before it gives up (0 = default; 1 forces the fail-soft path),
 // 7: text rows' FC1 -> GELU -> FC2 as one launch over hidden slices (ffn_txt.hip) on/off,
-// 8: gitcap_finalize_weights makes fragment-major copies of the text-path weights on/off (takes effect at the next finalize).
+// 8: gitcap_finalize_weights makes fragment-major copies of the text-path weights on/off (takes effect at the next finalize),
+// 9: text attention launches of more units than CUs use 8-wave workgroups (two units per CU) on/off.
 // Returns the old value.
 int gitcap_dbg_config(int key, int value) {
     int old = -1;
@@ -1313,6 +1314,7 @@ int gitcap_dbg_config(int key, int value) {
         case 6: old = (int)g_ln_spin_limit.exchange((unsigned)(value > 0 ? value : 0)); break;
         case 7: old = g_ffn_fuse.exchange(value != 0); break;
         case 8: old = g_wpack.exchange(value != 0); break;
+        case 9: old = g_txt8.exchange(value != 0); break;
         default: return GITCAP_ERR_ARG;
     }
     return old;

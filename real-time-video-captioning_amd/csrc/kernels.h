@@ -142,6 +142,7 @@ struct TxtBlockArgs {
     int nt_kv;                                  // 1: the K/V rows are streamed with non-temporal loads (they do not fit the caches anyway)
 };
 bool txt_block_ok(int D);
+extern std::atomic<bool> g_txt8;                                          // txtblock.hip: 8-wave workgroups where units > CUs (speed switch 9)
 hipError_t launch_txt_block(const TxtBlockArgs& a, hipStream_t s);
 
 // Small attention of the student decoder (student.hip): one wave per (query row, head), at most 64 keys,

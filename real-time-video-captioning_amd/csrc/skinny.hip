@@ -105,15 +105,32 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
     for (int r = 0; r < 4; ++r) bias[r] = (a.bias && n + r < a.N) ? a.bias[n + r] : 0.f;
 
     const int mtiles = (a.M + 15) >> 4;
+    // the activation fragments of m-tile mt + 1 are requested before the MFMAs of m-tile mt (32 or more rows: a second
+    // m-tile used to add a whole load -> MFMA -> store round trip to the launch)
+    bf16x8 xnext[LNR ? 1 : K32];
+    auto load_x = [&](int mt) {
+        if (LNR) return;
+        int m = mt * 16 + frow;
+        m = m < a.M ? m : a.M - 1;
+        const bf16_t* xp = a.X + (size_t)m * a.ldx + fq * 8;
+#pragma unroll
+        for (int k = 0; k < K32; ++k) xnext[LNR ? 0 : k] = *(const bf16x8*)(xp + k * 32);
+    };
+    load_x(0);
     for (int mt = 0; mt < mtiles; ++mt) {
         int m = mt * 16 + frow;
         const bool mvalid = m < a.M;
         m = mvalid ? m : a.M - 1;                               // clamp: padded rows are discarded
-        const bf16_t* xp = a.X + (size_t)m * a.ldx + fq * 8;
+        bf16x8 xcur[LNR ? 1 : K32];
+        if (!LNR) {
+#pragma unroll
+            for (int k = 0; k < K32; ++k) xcur[k] = xnext[k];
+            if (mt + 1 < mtiles) load_x(mt + 1);
+        }
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < K32; ++k) {
-            const bf16x8 xf = LNR ? *(const bf16x8*)(&xrow[m][fq * 8 + k * 32]) : *(const bf16x8*)(xp + k * 32);
+            const bf16x8 xf = LNR ? *(const bf16x8*)(&xrow[m][fq * 8 + k * 32]) : xcur[LNR ? 0 : k];
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k], xf, acc, 0, 0, 0);
         }
         // lane holds out[m][n .. n+3]
@@ -182,17 +199,26 @@ __global__ __launch_bounds__(64) void skinny_splitk_kernel(SkinnyArgs a) {
     const int n = n0 + fq * 4;
     float* slab = (float*)a.out + (size_t)ks * a.M * a.ldo;
     const int mtiles = (a.M + 15) >> 4;
+    bf16x8 xnext[K32];                                          // m-tile mt + 1's fragments in flight under m-tile mt (skinny_full)
+    auto load_x = [&](int mt) {
+        int m = mt * 16 + frow;
+        m = m < a.M ? m : a.M - 1;
+        const bf16_t* xp = a.X + (size_t)m * a.ldx + kbeg + fq * 8;
+#pragma unroll
+        for (int k = 0; k < K32; ++k) xnext[k] = *(const bf16x8*)(xp + k * 32);
+    };
+    load_x(0);
     for (int mt = 0; mt < mtiles; ++mt) {
         int m = mt * 16 + frow;
         const bool mvalid = m < a.M;
         m = mvalid ? m : a.M - 1;
-        const bf16_t* xp = a.X + (size_t)m * a.ldx + kbeg + fq * 8;
+        bf16x8 xcur[K32];
+#pragma unroll
+        for (int k = 0; k < K32; ++k) xcur[k] = xnext[k];
+        if (mt + 1 < mtiles) load_x(mt + 1);
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < K32; ++k) {
-            const bf16x8 xf = *(const bf16x8*)(xp + k * 32);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k], xf, acc, 0, 0, 0);
-        }
+        for (int k = 0; k < K32; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k], xcur[k], acc, 0, 0, 0);
         if (mvalid) *(f32x4*)(slab + (size_t)m * a.ldo + n) = acc;
     }
 }

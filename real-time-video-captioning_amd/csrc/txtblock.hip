@@ -20,6 +20,7 @@
 // ~30 GB/s whatever serves them (HBM, Infinity Cache or L2); 295 KB of q|k|v weights per (row, head) unit cost 10 us in
 // front of the attention, against 6 us for a launch of single-wave tiles that reads every weight byte once.
 #include "kernels.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace {
@@ -57,10 +58,17 @@ __device__ unsigned long long* g_txt_stamps;
 #define TXT_STAMP(i) do {} while (0)
 #endif
 
-// sum over the 16 waves of the block (fixed order); `red` is a 16-float LDS array no one else is using
-__device__ __forceinline__ float block_sum(float v, float* red, int tid) {
-    v = wave_sum(v);
-    if ((tid & 63) == 0) red[tid >> 6] = v;
+// The row is held as 16 "virtual waves" of 64 columns (column c = 64 v + lane).  With 16 physical waves a thread holds one
+// column (NC = 1); with 8 it holds columns tid and tid + 512, i.e. virtual waves wid and wid + 8 (NC = 2).  Each virtual
+// wave's 64 values are summed by the same butterfly, the 16 sums are added in virtual-wave order: the same bits whatever
+// the workgroup size.  `red` is a 16-float LDS array no one else is using.
+template <int NC>
+__device__ __forceinline__ float block_sum(const float (&v)[NC], float* red, int tid) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float s = wave_sum(v[c]);
+        if ((tid & 63) == 0) red[(tid >> 6) + c * (16 / NC)] = s;
+    }
     __syncthreads();
     float s = 0.f;
 #pragma unroll
@@ -68,29 +76,45 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
     return s;
 }
 
-// y = LayerNorm over the D values held one per thread (tid < D); g, b = this thread's gamma / beta (loaded by the caller
-// together with its other loads, so that they are not a round trip of their own behind the two block sums)
-__device__ __forceinline__ float block_layernorm(float v, bool act, int D, float eps, float g, float b,
-                                                 float (*red)[16], int tid) {
+// y = LayerNorm over the D values of the row (thread: columns tid + c * 1024 / NC while < D); g, b = the thread's gamma /
+// beta (loaded by the caller together with its other loads, so that they are not a round trip of their own behind the two
+// block sums)
+template <int NC>
+__device__ __forceinline__ void block_layernorm(float (&v)[NC], const bool (&act)[NC], int D, float eps, const float (&g)[NC],
+                                                const float (&b)[NC], float (*red)[16], int tid) {
 #pragma clang fp contract(off)
     TXT_STAMP(8);
-    const float mean = block_sum(act ? v : 0.f, red[0], tid) / (float)D;
+    float t[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) t[c] = act[c] ? v[c] : 0.f;
+    const float mean = block_sum<NC>(t, red[0], tid) / (float)D;
     TXT_STAMP(9);
-    const float d = act ? v - mean : 0.f;
-    const float rstd = rsqrtf(block_sum(d * d, red[1], tid) / (float)D + eps);
-    return act ? __builtin_fmaf(d * rstd, g, b) : 0.f;
+    float d[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { d[c] = act[c] ? v[c] - mean : 0.f; t[c] = d[c] * d[c]; }
+    const float rstd = rsqrtf(block_sum<NC>(t, red[1], tid) / (float)D + eps);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[c] = act[c] ? __builtin_fmaf(d[c] * rstd, g[c], b[c]) : 0.f;
 }
 
-template <int K32, bool FP8>
-__global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
+// NW = physical waves per workgroup: 16 (one unit per CU: the K/V stream of a long image prefix wants every wave of the CU),
+// or 8 (two units per CU, 72 KiB of LDS each) for launches of more units than CUs -- 32 single frames are 384 units of 50 KB
+// of K/V each, two rounds of 16-wave workgroups.  The keys are dealt to 16 VIRTUAL waves either way (virtual wave v takes
+// the 32-key groups v, v + 16, ...; a physical wave of the 8-wave form runs virtual waves wid and wid + 8 one after the
+// other) and every merge is in virtual-wave order, so both forms give the same bits (speed switch 9 / tests).
+template <int K32, bool FP8, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 4) void txt_block_kernel(TxtBlockArgs a) {
     constexpr int D = K32 * 32;
+    constexpr int NC = 16 / NW;                                 // columns (virtual waves) per thread in the row reducer
+    static_assert(NW == 16 || (NW == 8 && !FP8), "8-wave form: bf16 weights from the fragment-major copy only");
+    static_assert(NW == 16 || (D / 16) % 8 == 0, "8-wave form: whole out-projection tiles per wave");
     __shared__ __attribute__((aligned(16))) bf16_t ctxs[64];
     __shared__ float red[2][16];
     __shared__ float wsm[16][8][10];
     __shared__ int last_flag;
-    // per wave 8 KiB: the wave's first 32-key group (K 4 KiB | V 4 KiB) by LDS-DMA, then reused for the wave's
+    // per wave 8 KiB: the wave's first 32-key group (K 4 KiB | V 4 KiB) by LDS-DMA, then (16-wave form) reused for the wave's
     // output-dense weight fragments
-    __shared__ __attribute__((aligned(16))) char kvpre[16 * 8192];
+    __shared__ __attribute__((aligned(16))) char kvpre[NW * 8192];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -230,6 +254,22 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
             }
         }
     };
+    // lanes with equal sub merge their 8 key rows; the virtual wave's state goes to LDS
+    auto finish_virtual = [&](int vw) {
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            const float m2 = __shfl_xor(st.m, off), l2 = __shfl_xor(st.l, off);
+            float o2[8];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) o2[d] = __shfl_xor(st.o[d], off);
+            merge(st, m2, l2, o2);
+        }
+        if (kk == 0) {
+            wsm[vw][sub][0] = st.m; wsm[vw][sub][1] = st.l;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) wsm[vw][sub][2 + d] = st.o[d];
+        }
+    };
     {
         bf16x8 kA[4], vA[4], kB[4], vB[4];
         bool okA[4], okB[4];
@@ -237,9 +277,10 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
         if (g < Lk) {
             // Loads are issued unconditionally (a group past the last key reads key 0 and is masked): no branch
             // ever merges a loaded register with an undefined one, so nothing waits for a load before its use.
-            load_group(g + 512, kB, vB, okB);
+            if (NW == 16) load_group(g + 512, kB, vB, okB);
             // vmcnt counts in issue order: all but the 8 youngest operations (group 1's loads) done = group 0 is in LDS
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (NW == 16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 okA[u] = g + u * 8 + kk < Lk;
@@ -249,34 +290,40 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
             reduce_group(kA, vA, okA);                                     // (waits for the LDS reads)
             // the wave's 8 KiB are free again: its out-projection weight fragments arrive under the rest of the attention
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            dma_out_weights();
+            if (NW == 16) dma_out_weights();
             g += 512;
-            while (g < Lk) {                                               // kB holds group g
-                load_group(g + 512, kA, vA, okA);
-                reduce_group(kB, vB, okB);
-                g += 512;
-                if (g >= Lk) break;
-                load_group(g + 512, kB, vB, okB);
-                reduce_group(kA, vA, okA);
-                g += 512;
+            if (NW == 16) {
+                while (g < Lk) {                                           // kB holds group g
+                    load_group(g + 512, kA, vA, okA);
+                    reduce_group(kB, vB, okB);
+                    g += 512;
+                    if (g >= Lk) break;
+                    load_group(g + 512, kB, vB, okB);
+                    reduce_group(kA, vA, okA);
+                    g += 512;
+                }
+            } else {
+                // 8-wave form: one register set (128 VGPRs, two workgroups per CU: the other seven waves of the SIMD's
+                // four cover the round trip); the same groups in the same order
+                for (; g < Lk; g += 512) {
+                    load_group(g, kA, vA, okA);
+                    reduce_group(kA, vA, okA);
+                }
             }
-        } else {
+        } else if (NW == 16) {
             dma_out_weights();
         }
-    }
-    // merge the 8 key-groups of the wave (lanes with equal sub)
+        finish_virtual(wid);
+        if (NW == 8) {                                                     // the wave's second virtual wave: keys 32 (wid + 8) ...
+            st.m = -INFINITY; st.l = 0.f;
 #pragma unroll
-    for (int off = 8; off < 64; off <<= 1) {
-        const float m2 = __shfl_xor(st.m, off), l2 = __shfl_xor(st.l, off);
-        float o2[8];
-#pragma unroll
-        for (int d = 0; d < 8; ++d) o2[d] = __shfl_xor(st.o[d], off);
-        merge(st, m2, l2, o2);
-    }
-    if (kk == 0) {
-        wsm[wid][sub][0] = st.m; wsm[wid][sub][1] = st.l;
-#pragma unroll
-        for (int d = 0; d < 8; ++d) wsm[wid][sub][2 + d] = st.o[d];
+            for (int d = 0; d < 8; ++d) st.o[d] = 0.f;
+            for (g = (wid + 8) * 32; g < Lk; g += 512) {
+                load_group(g, kA, vA, okA);
+                reduce_group(kA, vA, okA);
+            }
+            finish_virtual(wid + 8);
+        }
     }
     __syncthreads();
     if (tid < 8) {
@@ -292,6 +339,18 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
         v.z = pack_bf2(t.o[4] * inv, t.o[5] * inv); v.w = pack_bf2(t.o[6] * inv, t.o[7] * inv);
         *(uint4*)(ctxs + tid * 8) = v;                                     // context enters the out-projection as bf16
     }
+    // 8-wave form: the wave's out-projection fragments straight from the fragment-major copy into registers (two units share
+    // a CU: no LDS to park 12 KiB per wave in); requested here, in flight across the barrier that publishes the context
+    constexpr int NT8 = NW == 8 ? (D / 16 + 7) / 8 : 1;
+    bf16x8 ow[NT8][2];
+    if (NW == 8) {
+        asm volatile("" ::: "memory");                                     // not above the attention: its registers are taken
+#pragma unroll
+        for (int i = 0; i < NT8; ++i) {                                    // (D / 16) % 8 == 0: every wave has NT8 whole tiles
+            const bf16x8* wp = (const bf16x8*)a.aowpk + ((size_t)(wid + 8 * i) * K32 + head * 2) * 64 + lane;
+            ow[i][0] = wp[0]; ow[i][1] = wp[64];
+        }
+    }
     __syncthreads();
     TXT_STAMP(3);
 
@@ -300,8 +359,21 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the wave's own weight DMA (read by itself only)
         const bf16x8 c0 = *(const bf16x8*)(ctxs + fq * 8), c1 = *(const bf16x8*)(ctxs + 32 + fq * 8);
         float* pp = a.part + ((size_t)m * H + head) * D;
+        if (NW == 8) {
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
+            for (int i = 0; i < NT8; ++i) {
+                const int t = wid + 8 * i;
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ow[i][0], c0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ow[i][1], c1, acc, 0, 0, 0);
+                if (frow == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) __hip_atomic_store(pp + t * 16 + fq * 4 + e, acc[e], RLX_AGENT);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (NW == 16 ? NT : 0); ++i) {
             const int t = wid + 16 * i;
             if (t < D / 16) {
                 bf16x8 w0, w1;
@@ -338,24 +410,34 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
     TXT_STAMP(5);
     if (!last_flag) return;
     {
-        const bool act = tid < D;
-        float v = 0.f, g = 0.f, b = 0.f;
-        if (act) {
-            g = a.g1[tid]; b = a.b1[tid];
-            // all H partials are requested before the first add; summed in head order
-            float s = 0.f;
-            const float* pp = a.part + (size_t)m * H * D + tid;
-            for (int h0 = 0; h0 < H; h0 += 12) {
-                float p[12];
+        float v[NC], g[NC], b[NC];
+        bool act[NC];
 #pragma unroll
-                for (int h = 0; h < 12; ++h) p[h] = (h0 + h < H) ? __hip_atomic_load(pp + (size_t)(h0 + h) * D, RLX_AGENT) : 0.f;
+        for (int c = 0; c < NC; ++c) {
+            const int col = tid + c * NW * 64;
+            act[c] = col < D;
+            v[c] = 0.f; g[c] = 0.f; b[c] = 0.f;
+            if (act[c]) {
+                g[c] = a.g1[col]; b[c] = a.b1[col];
+                // all H partials are requested before the first add; summed in head order
+                float s = 0.f;
+                const float* pp = a.part + (size_t)m * H * D + col;
+                for (int h0 = 0; h0 < H; h0 += 12) {
+                    float p[12];
 #pragma unroll
-                for (int h = 0; h < 12; ++h) s += p[h];
+                    for (int h = 0; h < 12; ++h) p[h] = (h0 + h < H) ? __hip_atomic_load(pp + (size_t)(h0 + h) * D, RLX_AGENT) : 0.f;
+#pragma unroll
+                    for (int h = 0; h < 12; ++h) s += p[h];
+                }
+                v[c] = s + (a.aob[col] + a.xin[(size_t)m * D + col]);
             }
-            v = s + (a.aob[tid] + a.xin[(size_t)m * D + tid]);
         }
-        const float y = block_layernorm(v, act, D, a.eps, g, b, red, tid);
-        if (act) { a.xs[(size_t)m * D + tid] = y; a.xsb[(size_t)m * D + tid] = f2bf(y); }
+        block_layernorm<NC>(v, act, D, a.eps, g, b, red, tid);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int col = tid + c * NW * 64;
+            if (act[c]) { a.xs[(size_t)m * D + col] = v[c]; a.xsb[(size_t)m * D + col] = f2bf(v[c]); }
+        }
     }
     TXT_STAMP(6);
 }
@@ -363,6 +445,10 @@ __global__ __launch_bounds__(1024) void txt_block_kernel(TxtBlockArgs a) {
 }  // namespace
 
 bool txt_block_ok(int D) { return D == 128 || D == 768; }
+
+// 8-wave workgroups (two units per CU) for launches of more units than the device has CUs (speed only: same bits);
+// gitcap_dbg_config(9, 0) / GITCAP_NO_TXT8: always 16 waves
+std::atomic<bool> g_txt8{!(getenv("GITCAP_NO_TXT8") && atoi(getenv("GITCAP_NO_TXT8")))};
 
 hipError_t launch_txt_block(const TxtBlockArgs& a_in, hipStream_t s) {
     TxtBlockArgs a = a_in;
@@ -374,12 +460,19 @@ hipError_t launch_txt_block(const TxtBlockArgs& a_in, hipStream_t s) {
     const int unit = a.T == 1 ? a.beams : 1;
     a.Mh = ((M / unit + 1) / 2) * unit;
     const int grid = a.H == 12 ? 8 * (M + (a.Mh > M - a.Mh ? a.Mh : M - a.Mh)) : M * a.H;
+    const bool w8 = g_txt8 && !a.aoscale && a.aowpk && M * a.H > device_cus();
     const int key = a.D * 2 + (a.aoscale ? 1 : 0);
     switch (key) {
-        case 256: hipLaunchKernelGGL((txt_block_kernel<4, false>), dim3(grid), dim3(1024), 0, s, a); break;
-        case 257: hipLaunchKernelGGL((txt_block_kernel<4, true>), dim3(grid), dim3(1024), 0, s, a); break;
-        case 1536: hipLaunchKernelGGL((txt_block_kernel<24, false>), dim3(grid), dim3(1024), 0, s, a); break;
-        case 1537: hipLaunchKernelGGL((txt_block_kernel<24, true>), dim3(grid), dim3(1024), 0, s, a); break;
+        case 256:
+            if (w8) hipLaunchKernelGGL((txt_block_kernel<4, false, 8>), dim3(grid), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((txt_block_kernel<4, false, 16>), dim3(grid), dim3(1024), 0, s, a);
+            break;
+        case 257: hipLaunchKernelGGL((txt_block_kernel<4, true, 16>), dim3(grid), dim3(1024), 0, s, a); break;
+        case 1536:
+            if (w8) hipLaunchKernelGGL((txt_block_kernel<24, false, 8>), dim3(grid), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((txt_block_kernel<24, false, 16>), dim3(grid), dim3(1024), 0, s, a);
+            break;
+        case 1537: hipLaunchKernelGGL((txt_block_kernel<24, true, 16>), dim3(grid), dim3(1024), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

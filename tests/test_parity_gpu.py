@@ -206,6 +206,24 @@ def test_results_do_not_depend_on_speed_switches(captioner_cls):
         _, vis = m2.forward_image_enc(fr[:n])
         ids = m2.greedy_decode(fr[:n], max_len=12, stop="never")
         assert torch.equal(ids, base[1]) and torch.equal(m2.forward_decoder(ids[:, :-1], vis), base[2]), n
+    # key 9: text-attention launches of more (row, head) units than CUs run 8-wave workgroups, two per CU -- 24 single frames are
+    # 288 units per token step, their 12-position teacher-forced pass 3456; both forms deal the keys to the same 16 virtual waves
+    cfg1 = git_base(0)
+    m1 = captioner_cls(cfg1, synthetic_weights(cfg1, 0), max_batch=24, max_frames=1, max_text_len=12)
+    fr1 = make_frames(24, 1, cfg1.image_size, 29).cuda()
+
+    def run1():
+        _, vis = m1.forward_image_enc(fr1)
+        ids = m1.greedy_decode(fr1, max_len=12, stop="never")
+        return ids.clone(), m1.forward_decoder(ids[:, :-1], vis).clone()
+    base = run1()
+    old = lib.gitcap_dbg_config(9, 0)
+    assert old == 1
+    try:
+        got = run1()
+    finally:
+        lib.gitcap_dbg_config(9, old)
+    assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1])
     assert lib.gitcap_dbg_config(99, 0) < 0
 
 
