@@ -222,11 +222,12 @@ def other_configs(dev, note):
     D, V, Ld, S = cfg.dec_width, cfg.vocab_size, cfg.dec_layers, 10 * cfg.tokens_per_frame
     c4 = {"workload": "GIT-large (ViT-L/14), 4 clips x 10 frames, beam 4, 15 steps, e4m3-valued weights, device-resident search",
           "gflop_per_caption": 1975.0}
-    for storage in ("fp8_e4m3", "bf16"):
-        m = GitCaptioner(cfg, wq, device=dev, max_batch=B, max_frames=10, max_text_len=20, max_beams=beams, weight_dtype=storage)
+    for storage in ("fp8_e4m3", "bf16", "fp8_e4m3+fp8_ffn"):         # the last: FC1 / FC2 of the image rows on fp8 MFMA (opt-in compute)
+        m = GitCaptioner(cfg, wq, device=dev, max_batch=B, max_frames=10, max_text_len=20, max_beams=beams,
+                         weight_dtype=storage.split("+")[0], compute="fp8_ffn" if storage.endswith("fp8_ffn") else "bf16")
         dt = med_ms(lambda: m.infer(fr, beam_size=beams, max_steps=steps), n=5)
         di = med_ms(lambda: m.forward_image_enc(fr), n=5)
-        wbytes = (Ld * (4 * D * D + 2 * D * cfg.dec_ffn) + D * V) * (1.0 if storage == "fp8_e4m3" else 2.0)
+        wbytes = (Ld * (4 * D * D + 2 * D * cfg.dec_ffn) + D * V) * (1.0 if storage.startswith("fp8_e4m3") else 2.0)
         kv = sum(B * beams * Ld * 2 * (S + t + 1) * D * 2.0 for t in range(steps - 1))
         lp = dt - di
         c4[storage] = {"ms_per_batch": round(dt, 3), "captions_per_s": round(B * 1e3 / dt, 1),

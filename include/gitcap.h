@@ -87,6 +87,14 @@ int gitcap_finalize_weights(gitcap_t* h);
 typedef enum { GITCAP_W_BF16 = 0, GITCAP_W_FP8_E4M3 = 1 } gitcap_weight_storage;
 int gitcap_set_weight_storage(gitcap_t* h, int storage);
 /* device bytes of all loaded tensors (weights, scales, tables, biases) */
+/* Arithmetic of the image pass (north_star: "MFMA bf16/fp8 GEMMs"; BASELINE configs[4]).  GITCAP_COMPUTE_BF16 (default): every GEMM
+ * on bf16 operands.  GITCAP_COMPUTE_FP8_FFN (opt-in; needs e4m3 weight storage and 768- / 1024-wide models): FC1 and FC2 of the
+ * image rows run on v_mfma_f32_16x16x128_f8f6f4 with the e4m3 weight codes read as stored and activations quantised to e4m3 with a
+ * static scale (codes of value * 16, saturating at +-28) by the producing epilogues; everything else stays bf16.  Results differ from
+ * bf16 compute by the activation rounding (measured |dlogit| <= 0.3 of a spread of 4 on GIT-large: DESIGN.md par. 3 / 6); the oracle's
+ * counterpart is GitOracle(emulate_fp8_act="ffn"). */
+enum { GITCAP_COMPUTE_BF16 = 0, GITCAP_COMPUTE_FP8_FFN = 1 };
+int gitcap_set_compute(gitcap_t* h, int compute);
 int gitcap_weight_bytes(const gitcap_t* h, int64_t* bytes);
 
 /* Replaces: self.image_encoder(torch.stack(batch['image'])) + temporal add + cat(dim=1)
@@ -223,6 +231,10 @@ int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launche
  * kernel (M % 224 == 0, A readable 16 rows past M), 257 = that kernel on 256 rows. */
 int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float* resid, void* out,
                     int M, int N, int K, int epi, int tile, void* stream);
+/* The fp8 tile kernel (csrc/gemm_f8.hip): A8 [M][K] and W8 [N][K] OCP e4m3 codes (M, N multiples of 256, K of 128), out = acc * ascale *
+ * wscale[n] + bias; epi 4 -> fp32 [M][N], 0 -> bf16, 8 / 9 -> e4m3 codes of quick_gelu / erf_gelu (.) * out8_inv. */
+int gitcap_dbg_gemm_f8(const void* A8, const void* W8, const float* wscale, float ascale, const float* bias, void* out,
+                       int M, int N, int K, int epi, float out8_inv, void* stream);
 /* GEMM + bias [+ resid] followed by LayerNorm of the output rows (N = 768 or 1024).  post = 0: out_f32 = x = A W^T + bias +
  * resid, out_bf16 = LN(x) (pre-LN block); post = 1: out_f32 = out_bf16 = LN(x), resid may be NULL (post-LN block).
  * fused = 1: inside the 256x256 kernel (the tiles of a 256-row block exchange segment statistics); fused = 224 / 257: inside the

@@ -52,14 +52,26 @@ def _q8(x: torch.Tensor) -> torch.Tensor:
     return (x / s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) * s
 
 
+def _q8_static(x: torch.Tensor, scale: float) -> torch.Tensor:
+    """OCP e4m3 with ONE static power-of-two scale, straight from the fp32 value, saturating at +-448 x scale: what the
+    device's `compute="fp8_ffn"` epilogues write for the activation operand of the two FFN GEMMs (csrc/common.h:
+    pack_fp8x4; csrc/gemm_f8.hip)."""
+    return (x / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) * scale
+
+
+FP8_FFN_SCALE = 1.0 / 16.0      # static scale of the e4m3 FFN activations (codes cover +-28; gitcap/config.py: the same constant)
+
+
 class GitOracle:
     def __init__(self, cfg, weights: Dict[str, np.ndarray], emulate_bf16: bool = False,
                  threads: Optional[int] = None, emulate_fp8_act: bool = False):
         self.cfg = cfg
         self.bf = bool(emulate_bf16)
-        # opt-in fp8 MFMA compute of the IMAGE pass: the activation operand of every image-row GEMM (not the patch
-        # embedding, not the text rows) is e4m3 with a per-row power-of-two scale instead of bf16
-        self.f8 = bool(emulate_fp8_act)
+        # True (study, oracle/fp8_act_study.py): the activation operand of every image-row GEMM (not the patch embedding, not
+        # the text rows) is e4m3 with a per-row power-of-two scale instead of bf16.
+        # "ffn" (the device's opt-in compute="fp8_ffn"): only FC1 and FC2 of the image rows, e4m3 with the static scale
+        # FP8_FFN_SCALE, rounded straight from fp32.
+        self.f8 = emulate_fp8_act if emulate_fp8_act == "ffn" else bool(emulate_fp8_act)
         if threads:
             torch.set_num_threads(threads)
         self.w: Dict[str, torch.Tensor] = {}
@@ -73,7 +85,10 @@ class GitOracle:
     # ------------------------------------------------------------------ primitives
     def _lin(self, x, name, img: bool = False):
         """y = bf16(x) @ bf16(W)^T + b with fp32 accumulation (img: an image-row GEMM, e4m3 activations when emulate_fp8_act)."""
-        xin = _q8(_r(x, self.bf)) if (img and self.f8) else _r(x, self.bf)
+        if img and self.f8 == "ffn":
+            xin = _q8_static(x, FP8_FFN_SCALE) if (name.endswith("fc1") or name.endswith("fc2")) else _r(x, self.bf)
+        else:
+            xin = _q8(_r(x, self.bf)) if (img and self.f8) else _r(x, self.bf)
         return Fn.linear(xin, self.w[name + ".w"], self.w[name + ".b"])
 
     def _ln(self, x, name, eps):

@@ -38,6 +38,16 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, v);
 }
 
+// four floats -> four OCP e4m3 codes (round to nearest even, saturating at +-448): two v_cvt_pk_fp8_f32
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+    a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+    c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+    unsigned w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return w;
+}
+
 // 16-byte-chunk XOR swizzle for [rows][64 bf16] (128-B row) LDS tiles read with ds_read_b128 by
 // MFMA operand lanes (row = lane&15 or lane&31, chunk = k/8).  g(row) = (row>>1)&7 makes every
 // ds_read_b128 lane group hit 16 distinct 16-B slots of the 256-B bank row for both the

@@ -20,13 +20,15 @@ __device__ unsigned long long* g_ln_stamps;
 #define LN_STAMP(i) do {} while (0)
 #endif
 
-// ep: this wave's EPI_REGION bytes of LDS; mw / nw: first m / n of the wave's block
-template <int EPI>
+// ep: this wave's EPI_REGION bytes of LDS; mw / nw: first m / n of the wave's block.  SCALED (fp8 kernel): the accumulators
+// are first multiplied by ascale * wscale[n].
+template <int EPI, bool SCALED = false>
 __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& a, const f32x4 (&acc)[2][4][2][2], char* ep,
                                                    const int mw, const int nw, const int lane) {
     const int frow = lane & 15, fq = lane >> 4;
     constexpr bool OUT_BF16 = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16);
-    constexpr int ESZ = OUT_BF16 ? 2 : 4;
+    constexpr bool OUT_F8 = (EPI == EPI_BIAS_QGELU_F8 || EPI == EPI_BIAS_GELU_F8);
+    constexpr int ESZ = OUT_F8 ? 1 : OUT_BF16 ? 2 : 4;
     constexpr int RS = 64 * ESZ + 16;                      // padded row stride (bytes)
     constexpr int LPR = 64 * ESZ / 16;                     // lanes per row on the row-wise side (8 or 16)
     constexpr int RPI = 64 / LPR;                          // rows per wave-instruction (8 or 4)
@@ -40,20 +42,24 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& a, const f32x
             const int nl = i * 16 + fq * 4;
             f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
             if (EPI != EPI_PATCH_F32 && a.bias) bias4 = *(const f32x4*)(a.bias + nb + nl);
+            f32x4 sc4 = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (SCALED) sc4 = *(const f32x4*)(a.wscale + nb + nl) * a.ascale;       // powers of two: exact
 #pragma unroll
             for (int y = 0; y < 2; ++y)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int ml = y * 32 + j * 16 + frow;
-                    f32x4 v = acc[x][i][y][j] + bias4;
-                    if (EPI == EPI_BIAS_QGELU_BF16) {
+                    f32x4 v = SCALED ? acc[x][i][y][j] * sc4 + bias4 : acc[x][i][y][j] + bias4;
+                    if (EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_QGELU_F8) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = quick_gelu(v[r]);
-                    } else if (EPI == EPI_BIAS_GELU_BF16) {
+                    } else if (EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_BIAS_GELU_F8) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = erf_gelu(v[r]);
                     }
-                    if (OUT_BF16) {
+                    if (OUT_F8) {
+                        *(unsigned*)(ep + ml * RS + nl) = pack_fp8x4(v[0] * a.out8_inv, v[1] * a.out8_inv, v[2] * a.out8_inv, v[3] * a.out8_inv);
+                    } else if (OUT_BF16) {
                         uint2 o;
                         o.x = pack_bf2(v[0], v[1]);
                         o.y = pack_bf2(v[2], v[3]);
@@ -71,7 +77,9 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& a, const f32x
             const int m = mw + ml;
             const int n = nb + rc * (16 / ESZ);
             const uint4 raw = *(const uint4*)(ep + ml * RS + rc * 16);
-            if (OUT_BF16) {
+            if (OUT_F8) {
+                *(uint4*)((unsigned char*)a.out + (size_t)m * a.ldo + n) = raw;
+            } else if (OUT_BF16) {
                 *(uint4*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = raw;
             } else {
                 f32x4 v = __builtin_bit_cast(f32x4, raw);
@@ -117,7 +125,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // (sc1) statistics stores with s_waitcnt vmcnt(0) before the workgroup barrier that precedes the arrival, the arrival and
 // the poll are agent-scope atomics, and the statistics are fetched with sc1 loads issued after the poll succeeded (the
 // "write-through store; drain; flag" form of MI355X_MICROARCH.md; agent-scope fences measured 5.4 vs 1.9 us per exchange).
-template <bool POST>
+template <bool POST, bool SCALED = false>
 __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f32x4 (&acc)[2][4][2][2], char* smem,
                                                       const int m0, const int n0, const int tm, const int tn,
                                                       const int wid, const int wm, const int wn, const int lane) {
@@ -141,12 +149,14 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
             const int nl = i * 16 + fq * 4;
             f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
             if (a.bias) bias4 = *(const f32x4*)(a.bias + nb + nl);
+            f32x4 sc4 = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (SCALED) sc4 = *(const f32x4*)(a.wscale + nb + nl) * a.ascale;       // fp8 kernel: powers of two, exact
 #pragma unroll
             for (int y = 0; y < 2; ++y)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int ml = y * 32 + j * 16 + frow;
-                    *(f32x4*)(ep + ml * RS + nl * 4) = acc[x][i][y][j] + bias4;
+                    *(f32x4*)(ep + ml * RS + nl * 4) = SCALED ? acc[x][i][y][j] * sc4 + bias4 : acc[x][i][y][j] + bias4;
                 }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -238,6 +248,8 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
             o.x = pack_bf2(y[0], y[1]);
             o.y = pack_bf2(y[2], y[3]);
             *(uint2*)(a.ln_out + m * a.ld_ln + n) = o;
+            // fp8 compute: the e4m3 copy the next (fp8) GEMM reads, straight from the fp32 value
+            if (a.ln_out8) *(unsigned*)(a.ln_out8 + m * a.ld_ln8 + n) = pack_fp8x4(y[0] * a.ln_out8_inv, y[1] * a.ln_out8_inv, y[2] * a.ln_out8_inv, y[3] * a.ln_out8_inv);
         }
     }
 #ifdef LN_STAMPS

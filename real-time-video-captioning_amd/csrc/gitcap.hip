@@ -100,6 +100,9 @@ struct gitcap {
     ExchangeHealth xh;                  // host_logic.h: once raised, the handle runs GEMM + row kernel for good
     int cus = 256;                      // compute units of the handle's device
     int nslab_max = 16;                 // fp32 split-K slabs per text row the workspace holds
+    // opt-in fp8 MFMA compute of the image rows' FFN GEMMs (gitcap_set_compute; gemm_f8.hip): e4m3 activation operands
+    bool f8ffn = false;
+    unsigned char *hb8 = nullptr, *ffn8 = nullptr;   // [Mi][Dm] LayerNorm output / [Mi][Fm] GELU output as e4m3 codes of value * 16
     bf16_t *hb = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr, *patches = nullptr, *kv_img = nullptr;
     // workspace (text rows)
     float *xs = nullptr, *xs2 = nullptr, *slabs = nullptr, *part = nullptr, *amax_val = nullptr;
@@ -310,6 +313,8 @@ hipError_t resolve_weight(gitcap* h, const WRef& W, int N, int K, hipStream_t s,
 hipError_t launch_gemm_auto(gitcap* h, GemmArgs a, int epi, hipStream_t s, int rows, int cap) {
     const bool ln = epi == EPI_RESID_LN_PRE || epi == EPI_RESID_LN_POST;
     if (ln) { a.ln_fail = h->ln_fail; a.ln_spin_limit = g_ln_spin_limit; }
+    if (a.wscale) return launch_gemm256f8(a, epi, s);                 // e4m3 operands: one tile kernel, whatever the batch
+    if (a.ln_out8 && ln) return launch_gemm256(a, epi, s);            // (its e4m3 LayerNorm copy: 256-row tiles only)
     if (gemm256_ok(a) && (a.M >> 8) * (a.N >> 8) >= g_small_tiles) {
         const bool allow224 = g_tile224 && (!h->pipelined || g_tile224_pipe == 1 || (g_tile224_pipe == 2 && (a.M >> 8) * (a.N >> 8) > h->cus));
         const int m224 = (rows + 223) / 224 * 224;
@@ -361,6 +366,30 @@ int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef
     return 0;
 }
 
+std::atomic<bool> g_fuse_ln{!env_flag("GITCAP_NO_GEMM_LN")};
+
+// compute = fp8_ffn: FC1 and FC2 of the image rows on v_mfma_f32_16x16x128_f8f6f4 (gemm_f8.hip).  Their activation operands
+// (the LayerNorm output in front of FC1, the GELU output in front of FC2) are written as e4m3 codes of value / kF8Scale by the
+// producing epilogues -- one static power-of-two scale, codes cover +-28, saturating --, the weights are the e4m3 codes of
+// e4m3 storage read as they are.  Everything else (q|k|v, attention, output projections, the text rows) stays bf16.  The e4m3
+// copy of a LayerNorm output exists only in the fused GEMM + LayerNorm epilogue, so the mode needs it (a handle whose exchange
+// timed out computes in bf16 from then on).
+constexpr float kF8Scale = 1.0f / 16.0f;
+bool use_f8(const gitcap* h) { return h->f8ffn && g_fuse_ln && !h->xh.degraded; }
+
+// FC1 of the image rows in fp8 compute: A8 = e4m3 codes [M][K] (value / kF8Scale), W = e4m3 storage; out8 = e4m3 codes of
+// GELU(A W^T + bias) / kF8Scale
+int gemm_f8(gitcap* h, hipStream_t s, int epi, const unsigned char* A8, int lda, const WRef& W, const float* bias, int rows,
+            int M, int N, int K, unsigned char* out8, int ldo) {
+    if (!W.scale) return fail(h, GITCAP_ERR_STATE, "fp8 compute needs e4m3 weight storage");
+    ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * rows * N * K, 1.0 * rows * K + 1.0 * N * K + 1.0 * rows * N);
+    GemmArgs a{};
+    a.A = (const bf16_t*)A8; a.lda = lda; a.W = (const bf16_t*)W.p; a.wscale = W.scale; a.ascale = kF8Scale; a.bias = bias;
+    a.M = M; a.N = N; a.K = K; a.out = out8; a.ldo = ldo; a.out8_inv = 1.0f / kF8Scale;
+    HIP_OK(h, launch_gemm_auto(h, a, epi, s, rows, h->Mi));
+    return 0;
+}
+
 // GEMM (+ bias [+ residual]) followed by LayerNorm of its output rows.
 //   post = false (pre-LN ViT block):   x = A W^T + bias + resid -> xout (fp32, may alias resid);  ln_b = bf16 LN(x)
 //   post = true  (post-LN decoder):    x = A W^T + bias [+ resid] -> scratch; xout = fp32 LN(x) (may alias resid); ln_b = bf16 LN(x)
@@ -368,24 +397,31 @@ int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef
 // statistics); small ones the 128x128 kernel + the row kernel.  Both give the same bits (ln_canon.h).
 // GITCAP_NO_GEMM_LN=1 (diagnosis / A-B only) keeps every LayerNorm a launch of its own; so does a handle whose exchange
 // ever timed out (poll_exchange).
-std::atomic<bool> g_fuse_ln{!env_flag("GITCAP_NO_GEMM_LN")};
 
 int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const WRef& W, const float* bias, int M, int N,
             int K, float* xout, const float* resid, const float* ln_g, const float* ln_b, float eps, int rows,
-            bf16_t* ln_out, float* scratch, const float* addv = nullptr, int add_div = 1, int add_mod = 1, float* ln_f32 = nullptr) {
+            bf16_t* ln_out, float* scratch, const float* addv = nullptr, int add_div = 1, int add_mod = 1, float* ln_f32 = nullptr,
+            unsigned char* ln8 = nullptr, bool f8in = false) {
+    // ln8 (fp8 compute): also write the LayerNorm output as e4m3 codes (the next FC1's operand).  f8in: A is e4m3 codes
+    // [M][lda bytes] and W the e4m3 storage (FC2 in fp8 compute).  Both exist in the fused epilogue only.
     GemmArgs a{};
     a.A = A; a.lda = lda; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = xout; a.ldo = N; a.resid = resid; a.ldr = N;
+    a.ln_out8 = ln8; a.ld_ln8 = N; a.ln_out8_inv = 1.0f / kF8Scale;
+    if (f8in) { a.W = (const bf16_t*)W.p; a.wscale = W.scale; a.ascale = kF8Scale; }
+    const bool force_fused = ln8 != nullptr || f8in;
     a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = eps; a.ln_out = ln_out; a.ld_ln = N; a.ln_stats = h->ln_stats; a.ln_cnt = h->ln_cnt;
     a.ln_stats_rows = h->Mi;
     a.ln_add = addv; a.ln_add_div = add_div; a.ln_add_mod = add_mod; a.ln_out_f32 = ln_f32; a.ld_ln_f32 = N; a.valid_rows = rows;
     // ln_out may be the A operand itself (visual projection): a tile writes its rows only after every tile that reads
     // them has finished its K loop (that is what the exchange waits for) -- as long as both views have the same row stride
     const bool alias_ok = (const void*)A != (const void*)ln_out || lda == N;
-    if (g_fuse_ln && !h->xh.degraded && alias_ok && gemm256_ln_ok(a) && (M >> 8) * (N >> 8) >= g_small_tiles &&
+    if (force_fused && !(g_fuse_ln && !h->xh.degraded && alias_ok && gemm256_ln_ok(a) && (post ? (xout && !addv && !ln_f32) : resid != nullptr)))
+        return fail(h, GITCAP_ERR_STATE, "fp8 compute: a GEMM + LayerNorm launch cannot take the fused epilogue");
+    if (g_fuse_ln && !h->xh.degraded && alias_ok && gemm256_ln_ok(a) && (force_fused || (M >> 8) * (N >> 8) >= g_small_tiles) &&
         (post ? (xout && !addv && !ln_f32) : resid != nullptr)) {
-        HIP_OK(h, resolve_weight(h, W, N, K, s, &a.W));
-        const double R = rows;              // A + W + fp32 out + bf16 LayerNorm out (+ fp32 residual read)
-        ProfScope ps(h, GITCAP_PROF_GEMM_LN, s, 2.0 * R * N * K, 2.0 * R * K + 2.0 * N * K + R * N * ((xout ? 4.0 : 0.0) + 2.0 + (ln_f32 ? 4.0 : 0.0) + (resid ? 4.0 : 0.0)));
+        if (!f8in) HIP_OK(h, resolve_weight(h, W, N, K, s, &a.W));
+        const double R = rows, esz = f8in ? 1.0 : 2.0;   // A + W + fp32 out + bf16 LayerNorm out (+ fp32 residual read)
+        ProfScope ps(h, GITCAP_PROF_GEMM_LN, s, 2.0 * R * N * K, esz * R * K + esz * N * K + R * N * ((xout ? 4.0 : 0.0) + 2.0 + (ln_f32 ? 4.0 : 0.0) + (resid ? 4.0 : 0.0)));
         HIP_OK(h, launch_gemm_auto(h, a, post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE, s, rows, h->Mi));
         return 0;
     }
@@ -430,6 +466,7 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
     if ((rc = gemm_ln(h, s, true, h->hb, Dv, h->vproj_w, h->vproj_b, Mp, D, Dv, h->x, nullptr, h->vproj_lnw, h->vproj_lnb,
                       c.proj_ln_eps, rows, h->hb, h->tmp))) return rc;
     const size_t kv_layer = (size_t)h->Mi * 3 * D;
+    const bool f8 = use_f8(h);
     const bool hid = h->want_hidden && h->cur_slot == 0;     // hidden-state export: synchronous path only
     auto keep = [&](int entry) -> hipError_t {
         return hid ? hipMemcpyAsync(h->hid_img + (size_t)entry * h->Mi * D, h->x, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, s) : hipSuccess;
@@ -439,10 +476,10 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
         const DecLayer& L = h->dec[l];
         bf16_t* kv = h->kv_img + (size_t)l * kv_layer;
         if (l + 1 < c.dec_layers || hid) {
-            {   // e4m3 storage: the layer's four matrices -> bf16 staging, one launch
+            {   // e4m3 storage: the layer's matrices -> bf16 staging, one launch (fp8 compute reads FC1 / FC2 as they are)
                 const WRef* ws[4] = {&L.qkvw, &L.aow, &L.fc1w, &L.fc2w};
                 const int wr[4] = {3 * D, D, c.dec_ffn, D}, wk[4] = {D, D, D, c.dec_ffn};
-                if ((rc = stage_layer(h, s, ws, wr, wk, 4))) return rc;
+                if ((rc = stage_layer(h, s, ws, wr, wk, f8 ? 2 : 4))) return rc;
             }
             if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, D, L.qkvw, L.qkvb, rows, Mp, 3 * D, D, kv, 3 * D))) return rc;
             {
@@ -450,10 +487,12 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
                 HIP_OK(h, launch_attn_full(kv, h->ctx, B, S, c.dec_heads, s));
             }
             if ((rc = gemm_ln(h, s, true, h->ctx, D, L.aow, L.aob, Mp, D, D, h->x, h->x, L.ln1w, L.ln1b, c.dec_ln_eps, rows,
-                              h->hb, h->tmp))) return rc;
-            if ((rc = gemm(h, s, EPI_BIAS_GELU_BF16, h->hb, D, L.fc1w, L.fc1b, rows, Mp, c.dec_ffn, D, h->ffn, c.dec_ffn))) return rc;
-            if ((rc = gemm_ln(h, s, true, h->ffn, c.dec_ffn, L.fc2w, L.fc2b, Mp, D, c.dec_ffn, h->x, h->x, L.ln2w, L.ln2b,
-                              c.dec_ln_eps, rows, h->hb, h->tmp))) return rc;
+                              h->hb, h->tmp, nullptr, 1, 1, nullptr, f8 ? h->hb8 : nullptr))) return rc;
+            if (f8) rc = gemm_f8(h, s, EPI_BIAS_GELU_F8, h->hb8, D, L.fc1w, L.fc1b, rows, Mp, c.dec_ffn, D, h->ffn8, c.dec_ffn);
+            else rc = gemm(h, s, EPI_BIAS_GELU_BF16, h->hb, D, L.fc1w, L.fc1b, rows, Mp, c.dec_ffn, D, h->ffn, c.dec_ffn);
+            if (rc) return rc;
+            if ((rc = gemm_ln(h, s, true, f8 ? (const bf16_t*)h->ffn8 : h->ffn, c.dec_ffn, L.fc2w, L.fc2b, Mp, D, c.dec_ffn, h->x, h->x, L.ln2w, L.ln2b,
+                              c.dec_ln_eps, rows, h->hb, h->tmp, nullptr, 1, 1, nullptr, nullptr, f8))) return rc;
             HIP_OK(h, keep(l + 1));
         } else {
             // last layer: image rows are only ever read as keys/values -> K,V projections only
@@ -967,12 +1006,13 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
     // pre-LN blocks: x += proj(attn(LN1 x)); x += fc2(qgelu(fc1(LN2 x))).  Each residual GEMM also produces the
     // LayerNorm its consumer needs (LN2 of this block / LN1 of the next; the last one ln_post + temporal embedding); the first
     // LN1 came out of the ln_pre pass above.
+    const bool f8 = use_f8(h);
     for (int i = 0; i < c.enc_layers; ++i) {
         const EncLayer& L = h->enc[i];
-        {   // e4m3 storage: the layer's four matrices -> bf16 staging, one launch
+        {   // e4m3 storage: the layer's matrices -> bf16 staging, one launch (fp8 compute reads FC1 / FC2 as they are)
             const WRef* ws[4] = {&L.qkvw, &L.projw, &L.fc1w, &L.fc2w};
             const int wr[4] = {3 * Dv, Dv, c.enc_ffn, Dv}, wk[4] = {Dv, Dv, Dv, c.enc_ffn};
-            if ((rc = stage_layer(h, s, ws, wr, wk, 4))) return rc;
+            if ((rc = stage_layer(h, s, ws, wr, wk, f8 ? 2 : 4))) return rc;
         }
         if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, Dv, L.qkvw, L.qkvb, rows, Mp, 3 * Dv, Dv, h->qkv, 3 * Dv))) return rc;
         {
@@ -980,20 +1020,24 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
             HIP_OK(h, launch_attn_full(h->qkv, h->ctx, nf, N, c.enc_heads, s));
         }
         if ((rc = gemm_ln(h, s, false, h->ctx, Dv, L.projw, L.projb, Mp, Dv, Dv, h->x, h->x, L.ln2w, L.ln2b, c.enc_ln_eps, rows,
-                          h->hb, nullptr))) return rc;
-        if ((rc = gemm(h, s, EPI_BIAS_QGELU_BF16, h->hb, Dv, L.fc1w, L.fc1b, rows, Mp, c.enc_ffn, Dv, h->ffn, c.enc_ffn))) return rc;
+                          h->hb, nullptr, nullptr, 1, 1, nullptr, f8 ? h->hb8 : nullptr))) return rc;
+        // FC1 + QuickGELU, FC2 (+ the next LayerNorm): bf16, or (compute = fp8_ffn) on e4m3 operands at twice the MFMA rate
+        const bf16_t* fc2_in = f8 ? (const bf16_t*)h->ffn8 : h->ffn;
+        if (f8) rc = gemm_f8(h, s, EPI_BIAS_QGELU_F8, h->hb8, Dv, L.fc1w, L.fc1b, rows, Mp, c.enc_ffn, Dv, h->ffn8, c.enc_ffn);
+        else rc = gemm(h, s, EPI_BIAS_QGELU_BF16, h->hb, Dv, L.fc1w, L.fc1b, rows, Mp, c.enc_ffn, Dv, h->ffn, c.enc_ffn);
+        if (rc) return rc;
         if (i + 1 < c.enc_layers) {
             const EncLayer& Nx = h->enc[i + 1];
-            if ((rc = gemm_ln(h, s, false, h->ffn, c.enc_ffn, L.fc2w, L.fc2b, Mp, Dv, c.enc_ffn, h->x, h->x, Nx.ln1w, Nx.ln1b,
-                              c.enc_ln_eps, rows, h->hb, nullptr))) return rc;
+            if ((rc = gemm_ln(h, s, false, fc2_in, c.enc_ffn, L.fc2w, L.fc2b, Mp, Dv, c.enc_ffn, h->x, h->x, Nx.ln1w, Nx.ln1b,
+                              c.enc_ln_eps, rows, h->hb, nullptr, nullptr, 1, 1, nullptr, nullptr, f8))) return rc;
         } else {
             // the last block's FC2 is followed by ln_post (+ per-frame temporal embedding, model.py:380); frames of a clip are
             // already adjacent rows, so the concat along tokens (model.py:382) is the identity on this layout.  x itself is
             // not needed any more.  The fp32 visual features (58 MB at B=16, F=6) are written straight into the caller's
             // buffer and only when asked for; the decoder consumes the bf16 copy.
             const float* addv = c.num_frames > 0 ? h->temporal : nullptr;
-            if ((rc = gemm_ln(h, s, false, h->ffn, c.enc_ffn, L.fc2w, L.fc2b, Mp, Dv, c.enc_ffn, nullptr, h->x, h->ln_post_w, h->ln_post_b,
-                              c.enc_ln_eps, rows, h->hb, nullptr, addv, N, F, visual_out))) return rc;
+            if ((rc = gemm_ln(h, s, false, fc2_in, c.enc_ffn, L.fc2w, L.fc2b, Mp, Dv, c.enc_ffn, nullptr, h->x, h->ln_post_w, h->ln_post_b,
+                              c.enc_ln_eps, rows, h->hb, nullptr, addv, N, F, visual_out, nullptr, f8))) return rc;
         }
     }
     return image_prefix(h, B, F * N, s);
@@ -1248,6 +1292,18 @@ int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float
     return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
 }
 
+// fp8 tile kernel (gemm_f8.hip) on caller-owned buffers: A8 [M][K], W8 [N][K] e4m3 codes, wscale [N], acc * ascale * wscale[n] + bias;
+// epi 4 -> out fp32 [M][N]; epi 0 -> bf16; epi 8 / 9 -> e4m3 codes of gelu(.) * out8_inv
+int gitcap_dbg_gemm_f8(const void* A8, const void* W8, const float* wscale, float ascale, const float* bias, void* out, int M, int N,
+                       int K, int epi, float out8_inv, void* stream) {
+    GemmArgs a{};
+    a.A = (const bf16_t*)A8; a.lda = K; a.W = (const bf16_t*)W8; a.wscale = wscale; a.ascale = ascale; a.bias = bias;
+    a.M = M; a.N = N; a.K = K; a.out = out; a.ldo = N; a.out8_inv = out8_inv;
+    if (epi != EPI_BIAS_F32 && epi != EPI_BIAS_BF16 && epi != EPI_BIAS_QGELU_F8 && epi != EPI_BIAS_GELU_F8) return GITCAP_ERR_ARG;
+    if (!gemm256f8_ok(a)) return GITCAP_ERR_ARG;
+    return launch_gemm256f8(a, epi, (hipStream_t)stream) == hipSuccess ? 0 : GITCAP_ERR_HIP;
+}
+
 // GEMM + bias [+ resid] + LayerNorm: fused = 1 the EPI_RESID_LN_* epilogue of the 256x256 kernel, 0 = GEMM (tile) then the
 // row kernel; post as in gemm_ln (gitcap.hip).  out_f32: post ? LN(x) : x.  Scratch for the exchange is allocated here.
 int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const float* resid, const float* gamma,
@@ -1363,6 +1419,29 @@ int gitcap_set_weight_storage(gitcap_t* h, int storage) {
     for (auto& kv : h->w)
         if (kv.second.loaded && kv.second.bf16) return fail(h, GITCAP_ERR_STATE, "set_weight_storage: call it before the first gitcap_load_tensor");
     h->fp8 = storage == GITCAP_W_FP8_E4M3;
+    return 0;
+}
+
+int gitcap_set_compute(gitcap_t* h, int compute) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "set_compute: null handle");
+    if (compute != GITCAP_COMPUTE_BF16 && compute != GITCAP_COMPUTE_FP8_FFN) return fail(h, GITCAP_ERR_ARG, "set_compute: unknown mode");
+    GUARD(h);
+    if (compute == GITCAP_COMPUTE_FP8_FFN) {
+        const gitcap_config& c = h->c;
+        if (!h->fp8) return fail(h, GITCAP_ERR_STATE, "set_compute(fp8_ffn): needs e4m3 weight storage (gitcap_set_weight_storage first)");
+        auto ok_ln = [](int n) { return n == 768 || n == 1024; };
+        if (!ok_ln(c.enc_width) || !ok_ln(c.dec_width) || c.enc_ffn % 256 || c.dec_ffn % 256)
+            return fail(h, GITCAP_ERR_ARG, "set_compute(fp8_ffn): widths must be 768 or 1024 and the FFN widths multiples of 256");
+        if (!h->hb8) {
+            const size_t Dm = std::max(h->Dv, h->D), Fm = std::max(c.enc_ffn, c.dec_ffn);
+            int rc = ws_alloc(h, &h->hb8, (size_t)h->Mi * Dm);
+            rc = rc ? rc : ws_alloc(h, &h->ffn8, (size_t)h->Mi * Fm);
+            if (rc) return rc;
+        }
+    }
+    HIP_OK(h, hipDeviceSynchronize());          // not between the launches of a submission in flight
+    h->f8ffn = compute == GITCAP_COMPUTE_FP8_FFN;
+    h->have_image = false;
     return 0;
 }
 

@@ -14,7 +14,10 @@ enum GemmEpi {
     // 256x256 kernel only, N = 768 or 1024: the tiles of one row block exchange LayerNorm statistics (ln_canon.h)
     // and each normalises its own columns -> the LayerNorm launch behind the GEMM and its re-read disappear.
     EPI_RESID_LN_PRE = 6,     // x = acc + bias + resid: out f32 = x (nullable), ln_out bf16 = LayerNorm(x) [+ ln_add] (pre-LN ViT block; ln_post)
-    EPI_RESID_LN_POST = 7     // x = acc + bias [+ resid]: out f32 = LayerNorm(x), ln_out bf16 = the same (post-LN decoder)
+    EPI_RESID_LN_POST = 7,    // x = acc + bias [+ resid]: out f32 = LayerNorm(x), ln_out bf16 = the same (post-LN decoder)
+    // fp8 kernel only (gemm_f8.hip): the GELU output as OCP e4m3 codes of y * out8_inv -- the activation operand of the next fp8 GEMM
+    EPI_BIAS_QGELU_F8 = 8,    // out e4m3 = quick_gelu(acc + bias)
+    EPI_BIAS_GELU_F8 = 9      // out e4m3 = erf_gelu(acc + bias)
 };
 struct GemmArgs {
     const bf16_t* A; int lda;     // activations [M][lda], M multiple of 128 (padded rows are junk)
@@ -35,6 +38,10 @@ struct GemmArgs {
     unsigned* ln_cnt;             // [row blocks][2] per row block {arrivals, generation}: zero before the first launch, self-resetting
     int ln_stats_rows;            // rows of ln_stats (>= M)
     int ln_rowblock_map;          // set by the launcher: workgroup -> tile map hands every XCD whole row blocks (host_logic.h)
+    // fp8 compute (gemm_f8.hip): A and W point at e4m3 codes; the accumulators are multiplied by ascale * wscale[n]
+    const float* wscale; float ascale;
+    float out8_inv;               // EPI_BIAS_*GELU_F8: 1 / (static scale of the e4m3 output)
+    unsigned char* ln_out8; int ld_ln8; float ln_out8_inv;   // nullable (EPI_RESID_LN_*): e4m3 copy of the LayerNorm output * ln_out8_inv
     unsigned* ln_fail;            // nullable: host-visible word raised when a tile gave up waiting for its siblings (no trap)
     unsigned ln_spin_limit;       // polls (~0.3 us each) before giving up; 0 = the default (~30 s)
 };
@@ -45,6 +52,8 @@ hipError_t launch_gemm64(const GemmArgs& a, int epi, hipStream_t s);    // 64x64
 bool gemm256_ok(const GemmArgs& a);
 hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);   // 256x256 tile, 8-wave ping-pong
 bool gemm256_ln_ok(const GemmArgs& a);                                   // shape the EPI_RESID_LN_* epilogues accept
+bool gemm256f8_ok(const GemmArgs& a);                                    // fp8 operands: K % 128 == 0, wscale / ascale set
+hipError_t launch_gemm256f8(const GemmArgs& a, int epi, hipStream_t s);  // the same tile kernel on e4m3 operands (gemm_f8.hip)
 // 256(n) x tile_rows(m) tile, tile_rows = 224 or 256 (gemm_mt.hip): M % tile_rows == 0; with 224 the A buffer must be readable
 // 16 rows past M.  Same bits as every other tile kernel.
 bool gemm_mt_ok(const GemmArgs& a, int tile_rows);

@@ -23,6 +23,7 @@ SYMBOLS = {
     "gitcap_hidden_states_enable": (c_int, [c_void_p, c_int]),
     "gitcap_hidden_states_read": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gitcap_set_weight_storage": (c_int, [c_void_p, c_int]),
+    "gitcap_set_compute": (c_int, [c_void_p, c_int]),
     "gitcap_weight_bytes": (c_int, [c_void_p, POINTER(c_int64)]),
     "gitcap_encode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "gitcap_set_visual": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -44,6 +45,7 @@ SYMBOLS = {
     "gitcap_dbg_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "gitcap_dbg_gemm_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                    c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gitcap_dbg_gemm_f8": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "gitcap_dbg_config": (c_int, [c_int, c_int]),
     "gitcap_dbg_attn_full": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gitcap_dbg_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p]),

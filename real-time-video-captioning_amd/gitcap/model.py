@@ -77,7 +77,7 @@ class GitCaptioner(nn.Module):
     def __init__(self, cfg: Optional[GitCapConfig] = None, weights: Optional[Mapping[str, np.ndarray]] = None, *,
                  device: str | torch.device = "cuda:0", max_batch: int = 16, max_frames: Optional[int] = None,
                  max_text_len: int = 32, max_beams: int = 1, tokenizer=None, stop: str = "all_sep",
-                 weight_dtype: str = "bf16",
+                 weight_dtype: str = "bf16", compute: str = "bf16",
                  # constructor kwargs of the reference student (model.py:55-57); only the ids/vocab matter here
                  vocab_length: Optional[int] = None, cls_token_id: Optional[int] = None,
                  sep_token_id: Optional[int] = None, **_ignored_student_kwargs):
@@ -100,8 +100,13 @@ class GitCaptioner(nn.Module):
         if weight_dtype not in ("bf16", "fp8_e4m3"):
             raise ValueError("weight_dtype must be 'bf16' or 'fp8_e4m3'")
         self.weight_dtype = weight_dtype
+        if compute not in ("bf16", "fp8_ffn"):
+            raise ValueError("compute must be 'bf16' or 'fp8_ffn'")
+        if compute == "fp8_ffn" and weight_dtype != "fp8_e4m3":
+            raise ValueError("compute='fp8_ffn' needs weight_dtype='fp8_e4m3' (the fp8 GEMMs read the e4m3 codes as stored)")
+        self.compute = compute
         self._kw = dict(max_batch=max_batch, max_frames=max_frames, max_text_len=max_text_len,
-                        max_beams=max_beams, stop=stop, weight_dtype=weight_dtype)
+                        max_beams=max_beams, stop=stop, weight_dtype=weight_dtype, compute=compute)
         self._dev = torch.device(device)
         self._handle = None
         self._weights: Optional[Dict[str, np.ndarray]] = None
@@ -133,6 +138,8 @@ class GitCaptioner(nn.Module):
         self._handle = h
         if self.weight_dtype == "fp8_e4m3":     # GEMM weights live in HBM as e4m3 + per-row 2^k scale (half the bytes)
             self._call("gitcap_set_weight_storage", 1)
+        if self.compute == "fp8_ffn":           # FC1 / FC2 of the image rows on fp8 MFMA (include/gitcap.h: gitcap_set_compute)
+            self._call("gitcap_set_compute", 1)
 
     def __del__(self):
         try:

@@ -216,3 +216,31 @@ def test_gemm_224_row_tiles_layernorm_epilogue(lib, M, N, K, post):
     x = A[:M].float() @ W.float().t() + bias + resid[:M]
     ln = torch.nn.functional.layer_norm(x, (N,), gamma, beta, 1e-5)
     assert torch.allclose(outs[1][0], ln if post else x, rtol=1e-4, atol=2e-4 * K ** 0.5)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 1024, 1024), (768, 4096, 1024), (512, 1024, 4096), (256, 768, 3072)])
+def test_gemm_fp8_vs_fp32_reference(lib, M, N, K):
+    """gemm_f8.hip (v_mfma_f32_16x16x128_f8f6f4): e4m3 codes in, exact products, fp32 accumulation -- against the fp32
+    matmul of the dequantised operands; then the e4m3-output GELU epilogues against the same reference rounded to e4m3."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a_f = (torch.randn(M, K, device="cuda", generator=g) * 1.5).clamp(-27, 27)
+    w_f = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    ascale = 1.0 / 16.0
+    A8 = (a_f / ascale).to(torch.float8_e4m3fn)
+    wscale = torch.exp2(torch.ceil(torch.log2(w_f.abs().amax(dim=1) / 448.0)))          # power of two per row
+    W8 = (w_f / wscale[:, None]).to(torch.float8_e4m3fn)
+    bias = torch.linspace(-1, 1, N, device="cuda")
+    ref = (A8.float() * ascale) @ (W8.float() * wscale[:, None]).t() + bias
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    rc = lib.gitcap_dbg_gemm_f8(_p(A8), _p(W8), _p(wscale), ascale, _p(bias), _p(out), M, N, K, 4, 0.0, _stream())
+    assert rc == 0
+    assert torch.allclose(out, ref, rtol=1e-3, atol=1e-3), float((out - ref).abs().max())
+    for epi, act in ((8, lambda x: x * torch.sigmoid(1.702 * x)), (9, torch.nn.functional.gelu)):
+        o8 = torch.empty(M, N, device="cuda", dtype=torch.uint8)
+        assert lib.gitcap_dbg_gemm_f8(_p(A8), _p(W8), _p(wscale), ascale, _p(bias), _p(o8), M, N, K, epi, 16.0, _stream()) == 0
+        got = o8.view(torch.float8_e4m3fn).float() / 16.0
+        want = (act(ref) * 16.0).clamp(-448, 448).to(torch.float8_e4m3fn).float() / 16.0
+        # a value on an e4m3 rounding boundary may fall either way (the GELU differs in the last bits): one e4m3 step
+        step = torch.maximum(want.abs() * 2 ** -3, torch.full_like(want, 2 ** -9 / 16.0 * 8))
+        assert bool(((got - want).abs() <= step + 1e-6).all()), float(((got - want).abs() / step).max())
+        assert float((got != want).float().mean()) < 0.02

@@ -494,6 +494,55 @@ def test_fp8_weight_values_config4(captioner_cls):
     assert m.infer(fr, beam_size=4, max_steps=6)["predictions"].shape == (2, 6)
 
 
+def test_fp8_ffn_compute(captioner_cls):
+    """compute="fp8_ffn" (north_star "MFMA bf16/fp8 GEMMs"; include/gitcap.h: gitcap_set_compute): FC1 / FC2 of the image rows on
+    v_mfma_f32_16x16x128_f8f6f4 with e4m3 activations (static scale 1/16) and the e4m3 weight codes as stored.  Against the
+    oracle evaluated with the same rounding points (GitOracle(emulate_fp8_act="ffn")) on a reduced 768-wide model: visual
+    features and teacher-forced logits within the fp8 tolerance, the quantisation really in effect (differs from bf16 compute by
+    more than it differs from its oracle), batch invariance and determinism as in bf16, and the bf16 default untouched."""
+    from gitcap.config import GitCapConfig
+    from gitcap.weights import quantize_weights_fp8
+    cfg = GitCapConfig(image_size=64, patch_size=16, enc_width=768, enc_layers=2, enc_heads=12, enc_ffn=3072, dec_width=768,
+                       dec_layers=2, dec_heads=12, dec_ffn=3072, vocab_size=997, max_text_pos=64, num_frames=3)
+    wq = quantize_weights_fp8(synthetic_weights(cfg, 0))
+    fr = make_frames(3, 3, cfg.image_size, 19)
+    ids = torch.tensor([[101, 5, 9, 7], [101, 77, 3, 2], [101, 500, 41, 8]])
+    m8 = captioner_cls(cfg, wq, max_batch=3, max_text_len=8, weight_dtype="fp8_e4m3", compute="fp8_ffn")
+    mb = captioner_cls(cfg, wq, max_batch=3, max_text_len=8, weight_dtype="fp8_e4m3")
+    o8 = GitOracle(cfg, wq, emulate_bf16=True, emulate_fp8_act="ffn")
+    ob = GitOracle(cfg, wq, emulate_bf16=True)
+    _, v8 = m8.forward_image_enc(fr)
+    l8 = m8.forward_decoder(ids, v8).cpu()
+    _, vb = mb.forward_image_enc(fr)
+    lb = mb.forward_decoder(ids, vb).cpu()
+    with torch.no_grad():
+        ov8, om8 = o8.forward_image_enc(fr)
+        ol8 = o8.decoder_text(o8.image_kv(om8), ids)
+        ovb, omb = ob.forward_image_enc(fr)
+        olb = ob.decoder_text(ob.image_kv(omb), ids)
+    assert (lb - olb).abs().max() < LOGIT_TOL_EMUL * 1.5, float((lb - olb).abs().max())        # bf16 compute: unchanged
+    d8 = float((l8 - ol8).abs().max())
+    # an e4m3 rounding boundary moves a value by 6 % where a bf16 one moves it by 0.4 %: the device-vs-oracle noise is larger
+    assert d8 < 3 * LOGIT_TOL_EMUL, d8
+    assert float((v8.cpu() - ov8).abs().max()) < 0.25
+    assert float((l8 - lb).abs().max()) > 0.02 and float((ol8 - olb).abs().max()) > 0.02       # the mode does something
+    # batch invariance and determinism hold in fp8 compute too (same tile kernel whatever the batch)
+    _, v1 = m8.forward_image_enc(fr[1:2])
+    assert torch.equal(v1[0], v8[1])
+    assert torch.equal(m8.greedy_decode(fr, max_len=6, stop="never")[2:], m8.greedy_decode(fr[2:], max_len=6, stop="never"))
+    assert torch.equal(m8.greedy_decode(fr, max_len=6, stop="never"), m8.greedy_decode(fr, max_len=6, stop="never"))
+    got = m8.greedy_decode(fr, max_len=6, stop="never").cpu()
+    with torch.no_grad():                                   # teacher-force the fp8 oracle on the device's tokens (image rows through image_kv)
+        tl = o8.decoder_text(o8.image_kv(om8), got[:, :-1])
+    gap = tl.max(-1).values - tl.gather(2, got[:, 1:, None]).squeeze(-1)
+    assert float(gap.max()) < 3 * NEAR_TIE, float(gap.max())
+    with pytest.raises(ValueError, match="fp8_e4m3"):
+        captioner_cls(cfg, wq, max_batch=1, max_text_len=8, compute="fp8_ffn")                 # needs e4m3 storage
+    with pytest.raises(Exception, match="768 or 1024"):
+        ct = git_tiny(2)
+        captioner_cls(ct, quantize_weights_fp8(synthetic_weights(ct, 0)), max_batch=1, max_text_len=8, weight_dtype="fp8_e4m3", compute="fp8_ffn")
+
+
 def test_more_edge_inputs(captioner_cls):
     cfg = git_tiny(2)
     w = synthetic_weights(cfg, 0)
@@ -725,6 +774,40 @@ def test_config4_exact_fixture(captioner_cls, golden_dir):
                        per_node_beam_size=int(g["per_node_beam_size"]), on_device=False)
         assert torch.equal(host["predictions"].cpu(), want)
         del m
+
+
+def test_config4_fp8_ffn_compute(captioner_cls):
+    """BASELINE configs[4] at its real shape with compute="fp8_ffn" (FC1 / FC2 of the image rows on fp8 MFMA, e4m3 storage):
+    teacher-forced logits against the oracle evaluated with the same e4m3 rounding points, the distance to the bf16-emulating
+    oracle (what the mode costs in accuracy: the 0.3 bar of DESIGN.md par. 6), and the device-resident search against the host
+    operator."""
+    from gitcap.config import git_large
+    from gitcap.weights import quantize_weights_fp8
+    cfg = git_large(num_frames=10)
+    wq = quantize_weights_fp8(synthetic_weights(cfg, 0))
+    fr = make_frames(1, 10, cfg.image_size, 41)
+    m = captioner_cls(cfg, wq, max_batch=1, max_frames=10, max_text_len=16, max_beams=4, weight_dtype="fp8_e4m3", compute="fp8_ffn")
+    o8 = GitOracle(cfg, wq, emulate_bf16=True, emulate_fp8_act="ffn")
+    ob = GitOracle(cfg, wq, emulate_bf16=True)
+    ids = torch.tensor([[101, 2023, 2003, 1037, 3899]])
+    _, vis = m.forward_image_enc(fr)
+    lg = m.forward_decoder(ids, vis).cpu()
+    with torch.no_grad():
+        _, mem8 = o8.forward_image_enc(fr)
+        ikv8 = o8.image_kv(mem8)
+        l8 = o8.decoder_text(ikv8, ids)
+        _, memb = ob.forward_image_enc(fr)
+        lb = ob.decoder_text(ob.image_kv(memb), ids)
+    d_own, d_bf16 = float((lg - l8).abs().max()), float((lg - lb).abs().max())
+    print(f"configs[4] fp8_ffn: max |dlogit| device vs fp8-emulating oracle {d_own:.3f}, vs bf16-emulating oracle {d_bf16:.3f}, "
+          f"fp8 oracle vs bf16 oracle {float((l8 - lb).abs().max()):.3f}")
+    assert d_own < 3 * LOGIT_TOL_EMUL, d_own
+    assert d_bf16 < 0.45, d_bf16
+    # the searches run on the same kernels: device-resident == host operator, bitwise
+    out = m.infer(fr, beam_size=4, max_steps=15, length_penalty=0.6, on_device=True)
+    host = m.infer(fr, beam_size=4, max_steps=15, length_penalty=0.6, on_device=False)
+    assert out["predictions"].shape == (1, 15) and torch.equal(out["predictions"], host["predictions"])
+    assert torch.allclose(out["logprobs"].cpu(), host["logprobs"].cpu(), atol=1e-5)
 
 
 def test_device_beam_search_base_size(captioner_cls, golden_dir):

@@ -7,7 +7,7 @@ from gitcap.model import GitCaptioner
 from gitcap.weights import synthetic_weights, quantize_weights_fp8
 cfg = git_large(10); B = int(os.environ.get('B', '4'))
 wq = quantize_weights_fp8(synthetic_weights(cfg, 0))
-m = GitCaptioner(cfg, wq, max_batch=B, max_frames=10, max_text_len=20, max_beams=4, weight_dtype=os.environ.get('STORAGE', 'fp8_e4m3'))
+m = GitCaptioner(cfg, wq, max_batch=B, max_frames=10, max_text_len=20, max_beams=4, weight_dtype=os.environ.get('STORAGE', 'fp8_e4m3'), compute=os.environ.get('COMPUTE', 'bf16'))
 fr = torch.randn(B, 10, 3, 224, 224, device='cuda')
 for _ in range(int(os.environ.get('PASSES', '5'))): m.infer(fr, beam_size=4, max_steps=15)
 torch.cuda.synchronize()
