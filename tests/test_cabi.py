@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     txt = open(os.path.join(ROOT, "include", "gitcap.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(gitcap_[a-z_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(gitcap_[a-z0-9_]+)\s*\(", txt)))
 
 
 def test_header_symbols_are_bound_and_exported():
