@@ -102,19 +102,15 @@ __device__ __forceinline__ void block_layernorm(float (&v)[NC], const bool (&act
 // of K/V each, two rounds of 16-wave workgroups.  The keys are dealt to 16 VIRTUAL waves either way (virtual wave v takes
 // the 32-key groups v, v + 16, ...; a physical wave of the 8-wave form runs virtual waves wid and wid + 8 one after the
 // other) and every merge is in virtual-wave order, so both forms give the same bits (speed switch 9 / tests).
-template <int K32, bool FP8, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 4) void txt_block_kernel(TxtBlockArgs a) {
+template <int K32, bool FP8, int NW, bool NT_KV>
+__global__ __launch_bounds__(NW * 64, 4) void txt_block_kernel(TxtBlockArgs a) {
     constexpr int D = K32 * 32;
     constexpr int NC = 16 / NW;                                 // columns (virtual waves) per thread in the row reducer
-    static_assert(NW == 16 || (NW == 8 && !FP8), "8-wave form: bf16 weights from the fragment-major copy only");
     static_assert(NW == 16 || (D / 16) % 8 == 0, "8-wave form: whole out-projection tiles per wave");
     __shared__ __attribute__((aligned(16))) bf16_t ctxs[64];
     __shared__ float red[2][16];
     __shared__ float wsm[16][8][10];
     __shared__ int last_flag;
-    // per wave 8 KiB: the wave's first 32-key group (K 4 KiB | V 4 KiB) by LDS-DMA, then (16-wave form) reused for the wave's
-    // output-dense weight fragments
-    __shared__ __attribute__((aligned(16))) char kvpre[NW * 8192];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -150,25 +146,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 4) void txt_block_kernel(Txt
     // (profiles/r04_text_attention_head_major_kv_timing.txt).  Not worth a second GEMM epilogue and attention read path.)
     const bf16_t* img = a.kv_img + (size_t)clip * a.S_img * ld + D + head * 64 + sub * 8;
     const bf16_t* txt = a.kv_txt + (size_t)r * a.Tmax * ld + D + head * 64 + sub * 8;
-    char* mypre = kvpre + wid * 8192;
-    // group 0 of this wave (keys 32 wid .. +31) -> LDS, lane-linear (lane = kk*8 + sub, one 1-KiB piece per 8 keys)
-    auto dma_group0 = [&]() {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int key = wid * 32 + u * 8 + kk;
-            key = key < Lk ? key : 0;
-            const bf16_t* kp = key < a.S_img ? img + (size_t)key * ld : txt + (size_t)(key - a.S_img) * ld;
-            if (a.nt_kv) {
-                __builtin_amdgcn_global_load_lds(GLB_PTR(kp), LDS_PTR(mypre + u * 1024), 16, 0, 2);
-                __builtin_amdgcn_global_load_lds(GLB_PTR(kp + D), LDS_PTR(mypre + 4096 + u * 1024), 16, 0, 2);
-            } else {
-                __builtin_amdgcn_global_load_lds(GLB_PTR(kp), LDS_PTR(mypre + u * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(GLB_PTR(kp + D), LDS_PTR(mypre + 4096 + u * 1024), 16, 0, 0);
-            }
-        }
-    };
-    if (wid * 32 < Lk) dma_group0();
-
     TXT_STAMP(2);
     // ---- 1: attention of (row, position tq, head) ------------------------------------------------------------------
     float qv[8];
@@ -191,13 +168,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 4) void txt_block_kernel(Txt
             valid[u] = key < Lk;
             key = valid[u] ? key : 0;
             const bf16_t* kp = key < a.S_img ? img + (size_t)key * ld : txt + (size_t)(key - a.S_img) * ld;
-            if (a.nt_kv) {      // read once per launch and too large to stay cached: do not displace what the GEMMs re-read
-                kf[u] = __builtin_nontemporal_load((const bf16x8*)kp);
-                vf[u] = __builtin_nontemporal_load((const bf16x8*)(kp + D));
-            } else {
-                kf[u] = *(const bf16x8*)kp;
-                vf[u] = *(const bf16x8*)(kp + D);
-            }
+            // NT_KV: read once per launch and too large to stay cached: do not displace what the GEMMs re-read.  (A template flag: a
+            // run-time branch around a load makes the compiler merge "loaded" with "not loaded" registers behind it and wait there.)
+            kf[u] = NT_KV ? __builtin_nontemporal_load((const bf16x8*)kp) : *(const bf16x8*)kp;
+            vf[u] = NT_KV ? __builtin_nontemporal_load((const bf16x8*)(kp + D)) : *(const bf16x8*)(kp + D);
         }
     };
     auto reduce_group = [&](const bf16x8* kf, const bf16x8* vf, const bool* valid) {
@@ -231,29 +205,6 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 4) void txt_block_kernel(Txt
             st.m = m_new;
         }
     };
-    constexpr int NT = (D / 16 + 15) / 16;                                 // out-projection: 16-column tiles per wave
-    auto dma_out_weights = [&]() {                                         // -> mypre, lane-linear
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const int t = wid + 16 * i;
-            if (t < D / 16) {
-                if (FP8) {      // e4m3: 8 bytes per lane and k-half, as two 4-byte pieces [tile][k-half][piece][lane]
-                    const unsigned char* wp = (const unsigned char*)a.aow + (size_t)(t * 16 + frow) * D + head * 64 + fq * 8;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        __builtin_amdgcn_global_load_lds(GLB_PTR(wp + (q >> 1) * 32 + (q & 1) * 4), LDS_PTR(mypre + (4 * i + q) * 256), 4, 0, 0);
-                } else if (a.aowpk) {   // bf16, fragment-major copy: k-steps 2 head, 2 head + 1 of tile t = 2 KiB contiguous
-                    const bf16_t* wp = (const bf16_t*)a.aowpk + (((size_t)t * K32 + head * 2) * 64 + lane) * 8;
-                    __builtin_amdgcn_global_load_lds(GLB_PTR(wp), LDS_PTR(mypre + (2 * i) * 1024), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds(GLB_PTR(wp + 512), LDS_PTR(mypre + (2 * i + 1) * 1024), 16, 0, 0);
-                } else {        // bf16: [tile][k-half][lane] 16 bytes
-                    const bf16_t* wp = (const bf16_t*)a.aow + (size_t)(t * 16 + frow) * D + head * 64 + fq * 8;
-                    __builtin_amdgcn_global_load_lds(GLB_PTR(wp), LDS_PTR(mypre + (2 * i) * 1024), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds(GLB_PTR(wp + 32), LDS_PTR(mypre + (2 * i + 1) * 1024), 16, 0, 0);
-                }
-            }
-        }
-    };
     // lanes with equal sub merge their 8 key rows; the virtual wave's state goes to LDS
     auto finish_virtual = [&](int vw) {
 #pragma unroll
@@ -275,25 +226,23 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 4) void txt_block_kernel(Txt
         bool okA[4], okB[4];
         int g = wid * 32;
         if (g < Lk) {
-            // Loads are issued unconditionally (a group past the last key reads key 0 and is masked): no branch
-            // ever merges a loaded register with an undefined one, so nothing waits for a load before its use.
-            if (NW == 16) load_group(g + 512, kB, vB, okB);
-            // vmcnt counts in issue order: all but the 8 youngest operations (group 1's loads) done = group 0 is in LDS
-            if (NW == 16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                okA[u] = g + u * 8 + kk < Lk;
-                kA[u] = *(const bf16x8*)(mypre + u * 1024 + lane * 16);
-                vA[u] = *(const bf16x8*)(mypre + 4096 + u * 1024 + lane * 16);
-            }
-            reduce_group(kA, vA, okA);                                     // (waits for the LDS reads)
-            // the wave's 8 KiB are free again: its out-projection weight fragments arrive under the rest of the attention
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (NW == 16) dma_out_weights();
-            g += 512;
+            // No LDS-DMA in this kernel: behind a global_load_lds the compiler's wait-count pass turns every wait for a register load
+            // into s_waitcnt vmcnt(0) ("pending FLAT"), so that the first reduce started when the LAST load in flight had landed
+            // and no reduce ever ran under the next group's loads (in-kernel stamps, profiles/r04_text_attention_phase_stamps.txt).
+            // Loads are issued unconditionally (a group past the last key reads key 0 and is masked): no branch ever merges a
+            // loaded register with an undefined one, so the waits the compiler counts are "all but the 8 youngest".
+            load_group(g, kA, vA, okA);
             if (NW == 16) {
-                while (g < Lk) {                                           // kB holds group g
+                // the first three groups (all there are at 6 frames) in straight-line code: branches around reduces only
+                load_group(g + 512, kB, vB, okB);
+                reduce_group(kA, vA, okA);
+                TXT_STAMP(11);
+                load_group(g + 1024, kA, vA, okA);
+                if (g + 512 < Lk) reduce_group(kB, vB, okB);
+                load_group(g + 1536, kB, vB, okB);
+                if (g + 1024 < Lk) reduce_group(kA, vA, okA);
+                g += 1536;
+                while (g < Lk) {                                           // longer prefixes: kB holds group g
                     load_group(g + 512, kA, vA, okA);
                     reduce_group(kB, vB, okB);
                     g += 512;
@@ -305,15 +254,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 4) void txt_block_kernel(Txt
             } else {
                 // 8-wave form: one register set (128 VGPRs, two workgroups per CU: the other seven waves of the SIMD's
                 // four cover the round trip); the same groups in the same order
-                for (; g < Lk; g += 512) {
+                reduce_group(kA, vA, okA);
+                for (g += 512; g < Lk; g += 512) {
                     load_group(g, kA, vA, okA);
                     reduce_group(kA, vA, okA);
                 }
             }
-        } else if (NW == 16) {
-            dma_out_weights();
         }
+        TXT_STAMP(12);
         finish_virtual(wid);
+        TXT_STAMP(13);
         if (NW == 8) {                                                     // the wave's second virtual wave: keys 32 (wid + 8) ...
             st.m = -INFINITY; st.l = 0.f;
 #pragma unroll
@@ -326,6 +276,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 4) void txt_block_kernel(Txt
         }
     }
     __syncthreads();
+    TXT_STAMP(14);
     if (tid < 8) {
 #pragma clang fp contract(off)
         Part t;
@@ -339,16 +290,30 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 4) void txt_block_kernel(Txt
         v.z = pack_bf2(t.o[4] * inv, t.o[5] * inv); v.w = pack_bf2(t.o[6] * inv, t.o[7] * inv);
         *(uint4*)(ctxs + tid * 8) = v;                                     // context enters the out-projection as bf16
     }
-    // 8-wave form: the wave's out-projection fragments straight from the fragment-major copy into registers (two units share
-    // a CU: no LDS to park 12 KiB per wave in); requested here, in flight across the barrier that publishes the context
-    constexpr int NT8 = NW == 8 ? (D / 16 + 7) / 8 : 1;
-    bf16x8 ow[NT8][2];
-    if (NW == 8) {
+    TXT_STAMP(15);
+    // the wave's out-projection fragments (its 16-column tiles x the head's two k-steps), requested here, in flight across the
+    // barrier that publishes the context: from the fragment-major copy, or from the row-major matrix (bf16, or e4m3 bytes x the
+    // row's power-of-two scale = the bf16-stored weight, bit for bit)
+    constexpr int NTW = (D / 16 + NW - 1) / NW;
+    constexpr bool WHOLE = (D / 16) % NW == 0;                             // every wave has NTW tiles (else: a guard per tile)
+    bf16x8 ow[NTW][2];
+    {
         asm volatile("" ::: "memory");                                     // not above the attention: its registers are taken
 #pragma unroll
-        for (int i = 0; i < NT8; ++i) {                                    // (D / 16) % 8 == 0: every wave has NT8 whole tiles
-            const bf16x8* wp = (const bf16x8*)a.aowpk + ((size_t)(wid + 8 * i) * K32 + head * 2) * 64 + lane;
-            ow[i][0] = wp[0]; ow[i][1] = wp[64];
+        for (int i = 0; i < NTW; ++i) {
+            const int t = WHOLE ? wid + NW * i : min(wid + NW * i, D / 16 - 1);      // (clamped: loaded, not used)
+            if (FP8) {
+                const unsigned char* wp = (const unsigned char*)a.aow + (size_t)(t * 16 + frow) * D + head * 64 + fq * 8;
+                const float sc = a.aoscale[t * 16 + frow];
+                ow[i][0] = fp8x8_to_bf16x8(*(const uint2*)wp, sc);
+                ow[i][1] = fp8x8_to_bf16x8(*(const uint2*)(wp + 32), sc);
+            } else if (a.aowpk) {
+                const bf16x8* wp = (const bf16x8*)a.aowpk + ((size_t)t * K32 + head * 2) * 64 + lane;
+                ow[i][0] = wp[0]; ow[i][1] = wp[64];
+            } else {
+                const bf16_t* wp = (const bf16_t*)a.aow + (size_t)(t * 16 + frow) * D + head * 64 + fq * 8;
+                ow[i][0] = *(const bf16x8*)wp; ow[i][1] = *(const bf16x8*)(wp + 32);
+            }
         }
     }
     __syncthreads();
@@ -356,43 +321,17 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 4) void txt_block_kernel(Txt
 
     // ---- 2: this head's share of the output dense ---------------------------------------------------------------
     {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the wave's own weight DMA (read by itself only)
         const bf16x8 c0 = *(const bf16x8*)(ctxs + fq * 8), c1 = *(const bf16x8*)(ctxs + 32 + fq * 8);
         float* pp = a.part + ((size_t)m * H + head) * D;
-        if (NW == 8) {
 #pragma unroll
-            for (int i = 0; i < NT8; ++i) {
-                const int t = wid + 8 * i;
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ow[i][0], c0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ow[i][1], c1, acc, 0, 0, 0);
-                if (frow == 0) {
+        for (int i = 0; i < NTW; ++i) {
+            const int t = wid + NW * i;
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ow[i][0], c0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ow[i][1], c1, acc, 0, 0, 0);
+            if (frow == 0 && (WHOLE || t < D / 16)) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) __hip_atomic_store(pp + t * 16 + fq * 4 + e, acc[e], RLX_AGENT);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < (NW == 16 ? NT : 0); ++i) {
-            const int t = wid + 16 * i;
-            if (t < D / 16) {
-                bf16x8 w0, w1;
-                if (FP8) {      // e4m3 x the row's power-of-two scale = the bf16-stored weight, bit for bit
-                    const unsigned* q = (const unsigned*)(mypre + (4 * i) * 256) + lane;
-                    const float sc = a.aoscale[t * 16 + frow];
-                    w0 = fp8x8_to_bf16x8(make_uint2(q[0], q[64]), sc);
-                    w1 = fp8x8_to_bf16x8(make_uint2(q[128], q[192]), sc);
-                } else {
-                    w0 = *(const bf16x8*)(mypre + (2 * i) * 1024 + lane * 16);
-                    w1 = *(const bf16x8*)(mypre + (2 * i + 1) * 1024 + lane * 16);
-                }
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, c0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, c1, acc, 0, 0, 0);
-                if (frow == 0) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) __hip_atomic_store(pp + t * 16 + fq * 4 + e, acc[e], RLX_AGENT);
-                }
+                for (int e = 0; e < 4; ++e) __hip_atomic_store(pp + t * 16 + fq * 4 + e, acc[e], RLX_AGENT);
             }
         }
     }
@@ -460,20 +399,20 @@ hipError_t launch_txt_block(const TxtBlockArgs& a_in, hipStream_t s) {
     const int unit = a.T == 1 ? a.beams : 1;
     a.Mh = ((M / unit + 1) / 2) * unit;
     const int grid = a.H == 12 ? 8 * (M + (a.Mh > M - a.Mh ? a.Mh : M - a.Mh)) : M * a.H;
-    const bool w8 = g_txt8 && !a.aoscale && a.aowpk && M * a.H > device_cus();
+    const bool w8 = g_txt8 && M * a.H > device_cus();
     const int key = a.D * 2 + (a.aoscale ? 1 : 0);
+#define TXT_LAUNCH(K32, F8) do { \
+        if (w8) { if (a.nt_kv) hipLaunchKernelGGL((txt_block_kernel<K32, F8, 8, true>), dim3(grid), dim3(512), 0, s, a); \
+                  else hipLaunchKernelGGL((txt_block_kernel<K32, F8, 8, false>), dim3(grid), dim3(512), 0, s, a); } \
+        else { if (a.nt_kv) hipLaunchKernelGGL((txt_block_kernel<K32, F8, 16, true>), dim3(grid), dim3(1024), 0, s, a); \
+               else hipLaunchKernelGGL((txt_block_kernel<K32, F8, 16, false>), dim3(grid), dim3(1024), 0, s, a); } } while (0)
     switch (key) {
-        case 256:
-            if (w8) hipLaunchKernelGGL((txt_block_kernel<4, false, 8>), dim3(grid), dim3(512), 0, s, a);
-            else hipLaunchKernelGGL((txt_block_kernel<4, false, 16>), dim3(grid), dim3(1024), 0, s, a);
-            break;
-        case 257: hipLaunchKernelGGL((txt_block_kernel<4, true, 16>), dim3(grid), dim3(1024), 0, s, a); break;
-        case 1536:
-            if (w8) hipLaunchKernelGGL((txt_block_kernel<24, false, 8>), dim3(grid), dim3(512), 0, s, a);
-            else hipLaunchKernelGGL((txt_block_kernel<24, false, 16>), dim3(grid), dim3(1024), 0, s, a);
-            break;
-        case 1537: hipLaunchKernelGGL((txt_block_kernel<24, true, 16>), dim3(grid), dim3(1024), 0, s, a); break;
+        case 256: TXT_LAUNCH(4, false); break;
+        case 257: TXT_LAUNCH(4, true); break;
+        case 1536: TXT_LAUNCH(24, false); break;
+        case 1537: TXT_LAUNCH(24, true); break;
         default: return hipErrorInvalidValue;
     }
+#undef TXT_LAUNCH
     return hipGetLastError();
 }
