@@ -148,12 +148,15 @@ __global__ __launch_bounds__(NW * 64, 4) void txt_block_kernel(TxtBlockArgs a) {
     const bf16_t* txt = a.kv_txt + (size_t)r * a.Tmax * ld + D + head * 64 + sub * 8;
     TXT_STAMP(2);
     // ---- 1: attention of (row, position tq, head) ------------------------------------------------------------------
+    // q is requested first and converted only when the first two key groups have been requested as well (the conversion is the
+    // first thing that waits for a load: ahead of the requests it would hold them back by a round trip)
     float qv[8];
-    {
-        const bf16x8 q8 = *(const bf16x8*)(a.kv_txt + ((size_t)r * a.Tmax + tq) * ld + head * 64 + sub * 8);
+    const bf16x8 q8 = *(const bf16x8*)(a.kv_txt + ((size_t)r * a.Tmax + tq) * ld + head * 64 + sub * 8);
+    auto convert_q = [&]() {
+        __builtin_amdgcn_sched_barrier(0);          // (the scheduler would start unpacking q between the requests, waiting there)
 #pragma unroll
         for (int d = 0; d < 8; ++d) qv[d] = bf2f((bf16_t)q8[d]) * kScaleLog2e;
-    }
+    };
     Part st;
     st.m = -INFINITY; st.l = 0.f;
 #pragma unroll
@@ -235,11 +238,14 @@ __global__ __launch_bounds__(NW * 64, 4) void txt_block_kernel(TxtBlockArgs a) {
             if (NW == 16) {
                 // the first three groups (all there are at 6 frames) in straight-line code: branches around reduces only
                 load_group(g + 512, kB, vB, okB);
+                convert_q();
                 reduce_group(kA, vA, okA);
                 TXT_STAMP(11);
                 load_group(g + 1024, kA, vA, okA);
+                __builtin_amdgcn_sched_barrier(0);  // every request of a group goes out before the next reduce waits for anything
                 if (g + 512 < Lk) reduce_group(kB, vB, okB);
                 load_group(g + 1536, kB, vB, okB);
+                __builtin_amdgcn_sched_barrier(0);
                 if (g + 1024 < Lk) reduce_group(kA, vA, okA);
                 g += 1536;
                 while (g < Lk) {                                           // longer prefixes: kB holds group g
@@ -254,6 +260,7 @@ __global__ __launch_bounds__(NW * 64, 4) void txt_block_kernel(TxtBlockArgs a) {
             } else {
                 // 8-wave form: one register set (128 VGPRs, two workgroups per CU: the other seven waves of the SIMD's
                 // four cover the round trip); the same groups in the same order
+                convert_q();
                 reduce_group(kA, vA, okA);
                 for (g += 512; g < Lk; g += 512) {
                     load_group(g, kA, vA, okA);
