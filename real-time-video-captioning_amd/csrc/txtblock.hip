@@ -282,24 +282,8 @@ __global__ __launch_bounds__(NW * 64, 4) void txt_block_kernel(TxtBlockArgs a) {
             finish_virtual(wid + 8);
         }
     }
-    __syncthreads();
-    TXT_STAMP(14);
-    if (tid < 8) {
-#pragma clang fp contract(off)
-        Part t;
-        t.m = wsm[0][tid][0]; t.l = wsm[0][tid][1];
-#pragma unroll
-        for (int d = 0; d < 8; ++d) t.o[d] = wsm[0][tid][2 + d];
-        for (int w = 1; w < 16; ++w) merge(t, wsm[w][tid][0], wsm[w][tid][1], &wsm[w][tid][2]);
-        const float inv = 1.0f / t.l;
-        uint4 v;
-        v.x = pack_bf2(t.o[0] * inv, t.o[1] * inv); v.y = pack_bf2(t.o[2] * inv, t.o[3] * inv);
-        v.z = pack_bf2(t.o[4] * inv, t.o[5] * inv); v.w = pack_bf2(t.o[6] * inv, t.o[7] * inv);
-        *(uint4*)(ctxs + tid * 8) = v;                                     // context enters the out-projection as bf16
-    }
-    TXT_STAMP(15);
     // the wave's out-projection fragments (its 16-column tiles x the head's two k-steps), requested here, in flight across the
-    // barrier that publishes the context: from the fragment-major copy, or from the row-major matrix (bf16, or e4m3 bytes x the
+    // two barriers and the merge between them: from the fragment-major copy, or from the row-major matrix (bf16, or e4m3 bytes x the
     // row's power-of-two scale = the bf16-stored weight, bit for bit)
     constexpr int NTW = (D / 16 + NW - 1) / NW;
     constexpr bool WHOLE = (D / 16) % NW == 0;                             // every wave has NTW tiles (else: a guard per tile)
@@ -323,6 +307,32 @@ __global__ __launch_bounds__(NW * 64, 4) void txt_block_kernel(TxtBlockArgs a) {
             }
         }
     }
+    __syncthreads();
+    TXT_STAMP(14);
+    if (tid < 64) {
+        // The 16 virtual waves' states in order, one thread per context element (sub = tid >> 3, d = tid & 7: element tid of the
+        // head's 64): every thread runs the chain of maxima and scale factors and its own component of the sums -- the arithmetic
+        // of merge() for that component, bit for bit -- with all 48 values it needs requested before the first step.  (8 threads
+        // used to walk the chain for 9 components each, reading the next state from LDS at every step: 1.6 us of a 20 us launch.)
+#pragma clang fp contract(off)
+        const int sb = tid >> 3, dd = tid & 7;
+        float mw[16], lw[16], ov[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { mw[w] = wsm[w][sb][0]; lw[w] = wsm[w][sb][1]; ov[w] = wsm[w][sb][2 + dd]; }
+        float mm = mw[0], ll = lw[0], oo = ov[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) {
+            const float Mx = fmaxf(mm, mw[w]);
+            const float s1 = (mm == -INFINITY) ? 0.f : ex2(mm - Mx);
+            const float s2 = (mw[w] == -INFINITY) ? 0.f : ex2(mw[w] - Mx);
+            ll = __builtin_fmaf(ll, s1, lw[w] * s2);
+            oo = __builtin_fmaf(oo, s1, ov[w] * s2);
+            mm = Mx;
+        }
+        const float inv = 1.0f / ll;
+        ctxs[tid] = f2bf(oo * inv);                                        // context enters the out-projection as bf16
+    }
+    TXT_STAMP(15);
     __syncthreads();
     TXT_STAMP(3);
 
