@@ -3,12 +3,12 @@
 //
 // One 16-wave workgroup = one unit (text row m = (r, j), head):
 //   1. attention over the image keys of the row's clip + the text keys 0..t of the row.  q, k, v of the text rows were
-//      written to the text K/V cache by the q|k|v projection launch (skinny.hip).  K/V are streamed from HBM: the wave's
-//      first 32-key group by LDS-DMA (no registers while in flight), the others straight to VGPRs, 8 lanes per key,
+//      written to the text K/V cache by the q|k|v projection launch (skinny.hip).  K/V are streamed from HBM straight to
+//      VGPRs (two register sets: the loads of the next 32-key group are in flight while one is reduced), 8 lanes per key,
 //      per-group online softmax; wave w takes the 32-key groups w, w+16, ... so the summation order depends on the key
 //      count only (batch invariant, bitwise)
 //   2. this head's share of the output dense: ctx_h[64] . Wo[:, 64h:64h+64]^T -> part[m][head][D] (fp32, write-through);
-//      the 6 KiB of weight fragments a wave needs arrive by LDS-DMA under the attention
+//      the weight fragments a wave needs (6 KiB) are requested behind the attention and arrive across its merge
 //   3. the LAST of the H units of a row to arrive (ticket counter; no unit ever waits for another) sums the H partials
 //      in head order, adds bias + residual and applies LayerNorm -> x1 (fp32) and bf16(x1) for the FC1 launch.
 // This replaces three launches of the first version (attention, split-K output dense, reduce + LayerNorm) by one.
@@ -19,6 +19,14 @@
 // Why the q|k|v projection is NOT in here (measured, tools/probe/txtblock_probe.hip): a CU pulls weight fragments at
 // ~30 GB/s whatever serves them (HBM, Infinity Cache or L2); 295 KB of q|k|v weights per (row, head) unit cost 10 us in
 // front of the attention, against 6 us for a launch of single-wave tiles that reads every weight byte once.
+//
+// No LDS-DMA in this kernel (it had some until the middle of round 4: the first key group and the output-dense fragments): behind
+// a global_load_lds the compiler's wait-count pass takes the wave to have a FLAT operation pending and turns every wait for a
+// plain load into s_waitcnt vmcnt(0); a run-time branch around a load and a conditionally issued load do the same where the paths
+// meet.  The counted waits written in the source then never took effect -- the first reduce started when the last load in flight
+// had landed -- and three A/Bs of the load schedule measured nothing.  Rules kept here: plain loads only, issued unconditionally
+// (masked groups read key 0), cache policy as a template flag, branches around reduces but not around loads.  Stamps, the ISA
+// evidence and the matrix-core form that was tried instead: profiles/r04_text_attention_phase_stamps.txt.
 #include "kernels.h"
 #include <atomic>
 #include <cstdlib>
@@ -98,7 +106,7 @@ __device__ __forceinline__ void block_layernorm(float (&v)[NC], const bool (&act
 }
 
 // NW = physical waves per workgroup: 16 (one unit per CU: the K/V stream of a long image prefix wants every wave of the CU),
-// or 8 (two units per CU, 72 KiB of LDS each) for launches of more units than CUs -- 32 single frames are 384 units of 50 KB
+// or 8 (two units per CU) for launches of more units than CUs -- 32 single frames are 384 units of 50 KB
 // of K/V each, two rounds of 16-wave workgroups.  The keys are dealt to 16 VIRTUAL waves either way (virtual wave v takes
 // the 32-key groups v, v + 16, ...; a physical wave of the 8-wave form runs virtual waves wid and wid + 8 one after the
 // other) and every merge is in virtual-wave order, so both forms give the same bits (speed switch 9 / tests).

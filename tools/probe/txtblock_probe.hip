@@ -81,14 +81,14 @@ int main(int argc, char** argv) {
     unsigned long long tmin = ~0ull, tmax = 0;
     for (int b = 0; b < nblk; ++b) if (h[b * 16]) { tmin = std::min(tmin, h[b * 16]); for (int i = 0; i < 7; ++i) tmax = std::max(tmax, h[b * 16 + i]); }
     printf("first block start -> last stamp: %.2f us (s_memrealtime, 100 MHz)\n", (tmax - tmin) / 100.0);
-    const int seg[11][2] = {{0, 3}, {0, 10}, {10, 11}, {11, 12}, {12, 13}, {13, 14}, {14, 15}, {15, 3}, {3, 4}, {4, 5}, {5, 6}};
-    const char* names[11] = {"attention", " wave 0: group 0 in LDS", " wave 0: group 0 reduced", " wave 0: groups 1, 2 reduced", " wave 0: lane merge",
+    const int seg[10][2] = {{0, 3}, {0, 11}, {11, 12}, {12, 13}, {13, 14}, {14, 15}, {15, 3}, {3, 4}, {4, 5}, {5, 6}};
+    const char* names[10] = {"attention", " wave 0: first group reduced", " wave 0: other groups reduced", " wave 0: lane merge",
                              " barrier (slowest wave)", " merge of 16 states", " barrier + ctx", "out-proj + store drain", "ticket", "reducer (last unit only)"};
     std::vector<double> start;
     for (int b = 0; b < nblk; ++b) if (h[b * 16]) start.push_back((h[b * 16] - tmin) / 100.0);
     std::sort(start.begin(), start.end());
     printf("block start offsets: median %.2f us, max %.2f us (%zu active blocks)\n", start[start.size() / 2], start.back(), start.size());
-    for (int i = 0; i < 11; ++i) {
+    for (int i = 0; i < 10; ++i) {
         std::vector<double> d;
         for (int b = 0; b < nblk; ++b) if (h[b * 16 + seg[i][0]] && h[b * 16 + seg[i][1]]) d.push_back(((double)h[b * 16 + seg[i][1]] - (double)h[b * 16 + seg[i][0]]) / 100.0);
         if (d.empty()) continue;
