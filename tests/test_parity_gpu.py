@@ -19,7 +19,7 @@ import pytest
 import torch
 
 from gitcap.config import git_base, git_tiny
-from gitcap.weights import synthetic_weights
+from gitcap.weights import quantize_weights_fp8, synthetic_weights
 from oracle.git_oracle import GitOracle, make_frames
 
 pytestmark = pytest.mark.gpu
@@ -208,22 +208,35 @@ def test_results_do_not_depend_on_speed_switches(captioner_cls):
         assert torch.equal(ids, base[1]) and torch.equal(m2.forward_decoder(ids[:, :-1], vis), base[2]), n
     # key 9: text-attention launches of more (row, head) units than CUs run 8-wave workgroups, two per CU -- 24 single frames are
     # 288 units per token step, their 12-position teacher-forced pass 3456; both forms deal the keys to the same 16 virtual waves
+    # (in three handles: fragment-major bf16 weights, e4m3-stored weights, row-major bf16 weights -- the three ways the kernel
+    # fetches its output-dense fragments)
     cfg1 = git_base(0)
-    m1 = captioner_cls(cfg1, synthetic_weights(cfg1, 0), max_batch=24, max_frames=1, max_text_len=12)
+    w1 = synthetic_weights(cfg1, 0)
     fr1 = make_frames(24, 1, cfg1.image_size, 29).cuda()
+    for variant in ("packed", "e4m3", "row-major"):
+        old8 = lib.gitcap_dbg_config(8, 0) if variant == "row-major" else None
+        try:
+            if variant == "e4m3":
+                m1 = captioner_cls(cfg1, quantize_weights_fp8(w1), max_batch=24, max_frames=1, max_text_len=12, weight_dtype="fp8_e4m3")
+            else:
+                m1 = captioner_cls(cfg1, w1, max_batch=24, max_frames=1, max_text_len=12)
+        finally:
+            if old8 is not None:
+                lib.gitcap_dbg_config(8, old8)
 
-    def run1():
-        _, vis = m1.forward_image_enc(fr1)
-        ids = m1.greedy_decode(fr1, max_len=12, stop="never")
-        return ids.clone(), m1.forward_decoder(ids[:, :-1], vis).clone()
-    base = run1()
-    old = lib.gitcap_dbg_config(9, 0)
-    assert old == 1
-    try:
-        got = run1()
-    finally:
-        lib.gitcap_dbg_config(9, old)
-    assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1])
+        def run1():
+            _, vis = m1.forward_image_enc(fr1)
+            ids = m1.greedy_decode(fr1, max_len=12, stop="never")
+            return ids.clone(), m1.forward_decoder(ids[:, :-1], vis).clone()
+        base = run1()
+        old = lib.gitcap_dbg_config(9, 0)
+        assert old == 1
+        try:
+            got = run1()
+        finally:
+            lib.gitcap_dbg_config(9, old)
+        assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]), variant
+        del m1
     assert lib.gitcap_dbg_config(99, 0) < 0
 
 
