@@ -113,11 +113,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
     }
 
     // ---- epilogue: lane holds n = nb + 4*fq + {0..3}, m = mb + frow for each (i, j) ------------
+    // Everything the epilogue reads (bias vectors, the residual or position values) is requested before its first store: with
+    // LDS-DMA earlier in the kernel the compiler waits for a load with vmcnt(0), which on gfx9 also waits for every store issued
+    // before it -- "load, add, store" per fragment was one full round trip per fragment.
+    f32x4 bias_v[FN], add_v[(EPI == EPI_BIAS_RESID_F32 || EPI == EPI_PATCH_F32) ? FN : 1][(EPI == EPI_BIAS_RESID_F32 || EPI == EPI_PATCH_F32) ? FM : 1];
 #pragma unroll
     for (int i = 0; i < FN; ++i) {
         const int n = n0 + wn * (BN / 2) + i * 16 + fq * 4;
-        f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (EPI != EPI_PATCH_F32 && a.bias) bias4 = *(const f32x4*)(a.bias + n);
+        bias_v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EPI != EPI_PATCH_F32 && a.bias) bias_v[i] = *(const f32x4*)(a.bias + n);
+        if (EPI == EPI_BIAS_RESID_F32 || EPI == EPI_PATCH_F32) {
+#pragma unroll
+            for (int j = 0; j < FM; ++j) {
+                const int m = m0 + wm * (BM / 2) + j * 16 + frow;
+                if (EPI == EPI_BIAS_RESID_F32) add_v[i][j] = *(const f32x4*)(a.resid + (size_t)m * a.ldr + n);
+                else add_v[i][j] = *(const f32x4*)(a.pos + (size_t)(1 + min(m, a.valid_rows - 1) % a.patches_per_frame) * a.N + n);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+        const int n = n0 + wn * (BN / 2) + i * 16 + fq * 4;
+        const f32x4 bias4 = bias_v[i];
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
             const int m = m0 + wm * (BM / 2) + j * 16 + frow;
@@ -135,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
                 o.y = pack_bf2(v[2], v[3]);
                 *(uint2*)((bf16_t*)a.out + (size_t)m * a.ldo + n) = o;
             } else if (EPI == EPI_BIAS_RESID_F32) {
-                const f32x4 r4 = *(const f32x4*)(a.resid + (size_t)m * a.ldr + n);
+                const f32x4 r4 = add_v[EPI == EPI_BIAS_RESID_F32 ? i : 0][EPI == EPI_BIAS_RESID_F32 ? j : 0];
                 *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v + r4;
             } else if (EPI == EPI_BIAS_F32) {
                 *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;
@@ -143,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
                 if (m < a.valid_rows) {
                     const int frame = m / a.patches_per_frame;
                     const int patch = m - frame * a.patches_per_frame;
-                    const f32x4 p4 = *(const f32x4*)(a.pos + (size_t)(1 + patch) * a.N + n);
+                    const f32x4 p4 = add_v[EPI == EPI_PATCH_F32 ? i : 0][EPI == EPI_PATCH_F32 ? j : 0];
                     const size_t orow = (size_t)frame * a.tokens_per_frame + 1 + patch;
                     *(f32x4*)((float*)a.out + orow * a.ldo + n) = acc[i][j] + p4;
                 }

@@ -7,6 +7,7 @@
 // private LDS region (the operand stages are dead by then) and writes/reads global memory as full row
 // segments: 16 B per lane, 128 B (bf16) or 256 B (fp32) per row.
 #pragma once
+#include <type_traits>
 #include "kernels.h"
 #include "ln_canon.h"
 
@@ -33,6 +34,19 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& a, const f32x
     constexpr int LPR = 64 * ESZ / 16;                     // lanes per row on the row-wise side (8 or 16)
     constexpr int RPI = 64 / LPR;                          // rows per wave-instruction (8 or 4)
     const int rr = lane / LPR, rc = lane % LPR;            // row-wise role of this lane
+    // The bias (and scale) vectors of BOTH half-blocks are requested before the first store: a load between the two halves' stores
+    // is waited for with vmcnt(0) (LDS-DMA earlier in the kernel: the compiler counts nothing), and on gfx9 that also waits for
+    // every store of the first half to be acknowledged.
+    f32x4 bias8[2][4], sc8[2][SCALED ? 4 : 1];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n8 = nw + x * 64 + i * 16 + fq * 4;
+            bias8[x][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (EPI != EPI_PATCH_F32 && a.bias) bias8[x][i] = *(const f32x4*)(a.bias + n8);
+            if (SCALED) sc8[x][i] = *(const f32x4*)(a.wscale + n8) * a.ascale;       // powers of two: exact
+        }
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
         const int nb = nw + x * 64;                     // first n of this half-block
@@ -40,10 +54,8 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& a, const f32x
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int nl = i * 16 + fq * 4;
-            f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (EPI != EPI_PATCH_F32 && a.bias) bias4 = *(const f32x4*)(a.bias + nb + nl);
-            f32x4 sc4 = f32x4{1.f, 1.f, 1.f, 1.f};
-            if (SCALED) sc4 = *(const f32x4*)(a.wscale + nb + nl) * a.ascale;       // powers of two: exact
+            const f32x4 bias4 = bias8[x][i];
+            const f32x4 sc4 = SCALED ? sc8[x][SCALED ? i : 0] : f32x4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
             for (int y = 0; y < 2; ++y)
 #pragma unroll
@@ -141,6 +153,13 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
     unsigned my_gen = 0;
     if (threadIdx.x == 0) my_gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     f32x4 xr[2][16];
+    // The residual values of a half-block are requested TOGETHER, into the registers x will live in, before the first of them is
+    // used: written as "load, add, store" per row the compiler may not move a load above the previous row's store (out and resid
+    // are the same buffer in every caller) and waits with vmcnt(0) -- which on gfx9 counts stores too -- for each of them in turn:
+    // 32 round trips per wave, the "HBM-bound" 25 us of this epilogue (ISA: L W0 S L W0 S ...; profiles/r04_gemm_ln_epilogue_waits.txt).
+    // Same operations per element, same bits.  (The branch around the loads makes the compiler wait for all of them where the
+    // paths meet: exactly the wait wanted here.)
+    const bool HAS_RESID = a.resid != nullptr;             // (wave-uniform)
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
         const int nb = nw + x * 64;
@@ -159,13 +178,21 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
                     *(f32x4*)(ep + ml * RS + nl * 4) = SCALED ? acc[x][i][y][j] * sc4 + bias4 : acc[x][i][y][j] + bias4;
                 }
         }
+        if (HAS_RESID) {
+            __builtin_amdgcn_sched_barrier(0);      // behind the LDS writes above: the accumulators of this half are dead by now
+            // wave-uniform base per row group (SGPRs) + one 32-bit lane offset: 16 per-lane pointers would spill
+            const unsigned loff = ((unsigned)rr * (unsigned)a.ldr + rc * 4) * 4u;
+#pragma unroll
+            for (int it = 0; it < 16; ++it)
+                xr[x][it] = *(const f32x4*)((const char*)(a.resid + (size_t)(mw + it * 4) * a.ldr + nb) + (size_t)loff);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int ml = it * 4 + rr;
             const int m = mw + ml, n = nb + rc * 4;
             f32x4 v = *(const f32x4*)(ep + ml * RS + rc * 16);
-            if (a.resid) v += *(const f32x4*)(a.resid + (size_t)m * a.ldr + n);
+            if (HAS_RESID) v += xr[x][it];
             if (!POST && a.out) *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;      // x itself: the residual stream
             xr[x][it] = v;
             const float2 st = ln_seg_stats(v);
@@ -231,6 +258,10 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     LN_STAMP(6);
+    // (the optional per-row addend -- the temporal embedding on the last ViT block -- as a second instantiation: a load inside the
+    // loop, even one that is never executed, leaves a vmcnt(0) behind every row's stores)
+    auto phase2 = [&](auto has_add_c) {
+    constexpr bool HAS_ADD = decltype(has_add_c)::value;
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
         const int n = nw + x * 64 + rc * 4;
@@ -241,7 +272,7 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
             const float2 mr = row_lds[ml];
             f32x4 y = ln_apply(xr[x][it], mr.x, mr.y, g4, b4);
             const size_t m = (size_t)(mw + ml);
-            if (!POST && a.ln_add) y += *(const f32x4*)(a.ln_add + (size_t)(((mw + ml) / a.ln_add_div) % a.ln_add_mod) * a.N + n);
+            if (HAS_ADD) y += *(const f32x4*)(a.ln_add + (size_t)(((mw + ml) / a.ln_add_div) % a.ln_add_mod) * a.N + n);   // (one launch per step)
             if (!POST && a.ln_out_f32 && mw + ml < a.valid_rows) *(f32x4*)(a.ln_out_f32 + m * a.ld_ln_f32 + n) = y;
             if (POST) *(f32x4*)((float*)a.out + m * a.ldo + n) = y;
             uint2 o;
@@ -252,6 +283,8 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
             if (a.ln_out8) *(unsigned*)(a.ln_out8 + m * a.ld_ln8 + n) = pack_fp8x4(y[0] * a.ln_out8_inv, y[1] * a.ln_out8_inv, y[2] * a.ln_out8_inv, y[3] * a.ln_out8_inv);
         }
     }
+    };
+    if (!POST && a.ln_add) phase2(std::true_type{}); else phase2(std::false_type{});
 #ifdef LN_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LN_STAMP(7);

@@ -39,6 +39,7 @@
 //        W(t+1): vmcnt(6) in L2(t) (8t+4 / 8t+5) -> first read C3(t) (8t+7 / 8t+8).  A(t+1): vmcnt(4) in L3(t)
 //        (8t+6 / 8t+7) -> first read L0(t+1) (8t+8 / 8t+9).
 #include "gemm_epilogue.h"
+#include <type_traits>
 #include "host_logic.h"
 
 namespace {
@@ -60,7 +61,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_mt;
 // acc[i][j]: n = nw + i*16 + 4*(lane>>4) + r, m = mw + j*16 + (lane&15)
 template <int EPI, int NM>
 __device__ __forceinline__ void epilogue_block(const GemmArgs& a, const f32x4 (&acc)[4][8], const int j0, char* ep,
-                                               const int mw, const int nw, const int lane) {
+                                               const int mw, const int nw, const int lane, const f32x4 (&bias_v)[4]) {
     const int frow = lane & 15, fq = lane >> 4;
     constexpr bool OUT_BF16 = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_QGELU_BF16 || EPI == EPI_BIAS_GELU_BF16);
     constexpr int ESZ = OUT_BF16 ? 2 : 4;
@@ -71,8 +72,7 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& a, const f32x4 (&
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int nl = i * 16 + fq * 4;
-        f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (EPI != EPI_PATCH_F32 && a.bias) bias4 = *(const f32x4*)(a.bias + nw + nl);
+        const f32x4 bias4 = bias_v[i];
 #pragma unroll
         for (int j = 0; j < NM; ++j) {
             const int ml = j * 16 + frow;
@@ -158,6 +158,15 @@ __device__ __forceinline__ void epilogue_tile_ln(const GemmArgs& a, const f32x4 
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (j < nm) *(f32x4*)(ep + (j * 16 + frow) * RS + (i * 16 + fq * 4) * 4) = acc[i][j0 + j] + bias4[i];
+        // the residual values of the sub-block together, into the registers x will live in (gemm_epilogue.h: written as "load,
+        // add, store" per row every load waits with vmcnt(0) for itself and for the previous row's store)
+        if (a.resid) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned loff = ((unsigned)rr * (unsigned)a.ldr + rc * 4) * 4u;
+#pragma unroll
+            for (int it = 0; it < 16; ++it)
+                if (it < 4 * nm) xr[j0 * 4 + it] = *(const f32x4*)((const char*)(a.resid + (size_t)(mw + j0 * 16 + it * 4) * a.ldr + nw) + (size_t)loff);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
@@ -165,7 +174,7 @@ __device__ __forceinline__ void epilogue_tile_ln(const GemmArgs& a, const f32x4 
                 const int ml = it * 4 + rr;
                 const int m = mw + j0 * 16 + ml, n = nw + rc * 4;
                 f32x4 v = *(const f32x4*)(ep + ml * RS + rc * 16);
-                if (a.resid) v += *(const f32x4*)(a.resid + (size_t)m * a.ldr + n);
+                if (a.resid) v += xr[j0 * 4 + it];
                 if (!POST && a.out) *(f32x4*)((float*)a.out + (size_t)m * a.ldo + n) = v;      // x itself: the residual stream
                 xr[j0 * 4 + it] = v;
                 const float2 st = ln_seg_stats(v);
@@ -242,13 +251,17 @@ __device__ __forceinline__ void epilogue_tile_ln(const GemmArgs& a, const f32x4 
     __builtin_amdgcn_wave_barrier();
     const int n = nw + rc * 4;
     const f32x4 g4 = *(const f32x4*)(a.ln_g + n), b4 = *(const f32x4*)(a.ln_b + n);
+    // (two instantiations for the optional per-row addend: a load inside the loop, even one that is never executed, leaves a
+    // vmcnt(0) behind every row's stores)
+    auto phase2 = [&](auto has_add_c) {
+    constexpr bool HAS_ADD = decltype(has_add_c)::value;
 #pragma unroll
     for (int it = 0; it < 4 * MT; ++it) {
         const int ml = it * 4 + rr;
         const float2 mr = row_lds[ml];
         f32x4 y = ln_apply(xr[it], mr.x, mr.y, g4, b4);
         const size_t m = (size_t)(mw + ml);
-        if (!POST && a.ln_add) y += *(const f32x4*)(a.ln_add + (size_t)(((mw + ml) / a.ln_add_div) % a.ln_add_mod) * a.N + n);
+        if (HAS_ADD) y += *(const f32x4*)(a.ln_add + (size_t)(((mw + ml) / a.ln_add_div) % a.ln_add_mod) * a.N + n);
         if (!POST && a.ln_out_f32 && mw + ml < a.valid_rows) *(f32x4*)(a.ln_out_f32 + m * a.ld_ln_f32 + n) = y;
         if (POST) *(f32x4*)((float*)a.out + m * a.ldo + n) = y;
         uint2 o;
@@ -256,6 +269,8 @@ __device__ __forceinline__ void epilogue_tile_ln(const GemmArgs& a, const f32x4 
         o.y = pack_bf2(y[2], y[3]);
         *(uint2*)(a.ln_out + m * a.ld_ln + n) = o;
     }
+    };
+    if (!POST && a.ln_add) phase2(std::true_type{}); else phase2(std::false_type{});
 }
 
 template <int EPI, int MT>
@@ -453,8 +468,16 @@ __global__ __launch_bounds__(512, 2) void gemm_mt_kernel(GemmArgs a) {
         epilogue_tile_ln<EPI == EPI_RESID_LN_POST, MT>(a, acc, smem, m0, n0, tm, tn, wid, wm, wn, lane);
     } else {
         char* ep = smem + wid * EPI_REGION;
-        epilogue_block<EPI, 4>(a, acc, 0, ep, m0 + wm * WR, n0 + wn * 64, lane);
-        epilogue_block<EPI, NB>(a, acc, 4, ep, m0 + wm * WR, n0 + wn * 64, lane);
+        // the bias vectors once, before the first store: a load between the two sub-blocks' stores is waited for with vmcnt(0)
+        // (LDS-DMA earlier in the kernel: the compiler counts nothing), which on gfx9 also waits for every store before it
+        f32x4 bias_v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bias_v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (EPI != EPI_PATCH_F32 && a.bias) bias_v[i] = *(const f32x4*)(a.bias + n0 + wn * 64 + i * 16 + (lane >> 4) * 4);
+        }
+        epilogue_block<EPI, 4>(a, acc, 0, ep, m0 + wm * WR, n0 + wn * 64, lane, bias_v);
+        epilogue_block<EPI, NB>(a, acc, 4, ep, m0 + wm * WR, n0 + wn * 64, lane, bias_v);
     }
 }
 
