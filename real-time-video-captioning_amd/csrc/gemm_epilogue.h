@@ -160,16 +160,25 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
     // Same operations per element, same bits.  (The branch around the loads makes the compiler wait for all of them where the
     // paths meet: exactly the wait wanted here.)
     const bool HAS_RESID = a.resid != nullptr;             // (wave-uniform)
+    // (bias / scale vectors of both half-blocks before the first store, as in gemm_epilogue_wave)
+    f32x4 bias8[2][4], sc8[2][SCALED ? 4 : 1];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n8 = nw + x * 64 + i * 16 + fq * 4;
+            bias8[x][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.bias) bias8[x][i] = *(const f32x4*)(a.bias + n8);
+            if (SCALED) sc8[x][i] = *(const f32x4*)(a.wscale + n8) * a.ascale;       // fp8 kernel: powers of two, exact
+        }
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
         const int nb = nw + x * 64;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int nl = i * 16 + fq * 4;
-            f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (a.bias) bias4 = *(const f32x4*)(a.bias + nb + nl);
-            f32x4 sc4 = f32x4{1.f, 1.f, 1.f, 1.f};
-            if (SCALED) sc4 = *(const f32x4*)(a.wscale + nb + nl) * a.ascale;       // fp8 kernel: powers of two, exact
+            const f32x4 bias4 = bias8[x][i];
+            const f32x4 sc4 = SCALED ? sc8[x][SCALED ? i : 0] : f32x4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
             for (int y = 0; y < 2; ++y)
 #pragma unroll
