@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Memory operations and vmcnt waits of a kernel, in program order, from the compiler's assembly (no GPU needed).
+
+    python tools/isa_waits.py gemm256.hip 'gemm256_kernelILi6E'        # GEMM + residual + LayerNorm epilogue
+    python tools/isa_waits.py txtblock.hip 'txt_block_kernelILi24ELb0ELi16ELb1'
+
+Prints one token per instruction: L = global load (x4), l = narrower global load, D = global_load_lds (LDS-DMA), S / s / d =
+global store x4 / x2 / x1, BL / BS = buffer load / store, Wn = s_waitcnt vmcnt(n), | = s_barrier, xs / xl = scratch (spill)
+store / load, [ ] = a loop.  What to look for (profiles/r04_text_attention_phase_stamps.txt, r04_gemm_ln_epilogue_waits.txt):
+"L W0 S L W0 S" (every load waits for the previous store: on gfx9 vmcnt counts stores), W0 right behind a counted wait written
+in the source (LDS-DMA + plain loads in one kernel: the compiler stops counting), xs / xl inside a loop.
+"""
+import os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "real-time-video-captioning_amd", "csrc")
+
+
+def main():
+    if len(sys.argv) < 3:
+        sys.exit(__doc__)
+    src, pat = sys.argv[1], sys.argv[2]
+    src = src if os.path.exists(src) else os.path.join(CSRC, src)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form",
+               "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-S", "--cuda-device-only", "-o", out, src]
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        text = open(out).read().splitlines()
+    names = [l.split(":")[0] for l in text if re.match(r"^_Z\w+:", l)]
+    hits = [n for n in names if pat in n]
+    if not hits:
+        sys.exit("no kernel matches %r; kernels: %s" % (pat, ", ".join(names)))
+    for name in hits:
+        i = text.index(next(l for l in text if l.startswith(name + ":")))
+        toks, vg, sc = [], None, None
+        for l in text[i + 1:]:
+            t = l.strip()
+            if re.match(r"^_Z\w+:", l) or t.startswith(".section"):
+                pass
+            if t.startswith("; NumVgprs:"):
+                vg = t.split(":")[1].strip()
+            if t.startswith("; ScratchSize:"):
+                sc = t.split(":")[1].strip()
+                break
+            if "Loop Header" in t:
+                toks.append("[")
+            op = t.split()[0] if t and not t.startswith(";") and not t.startswith(".") else ""
+            if op.startswith("global_load_lds"):
+                toks.append("D")
+            elif op == "global_load_dwordx4":
+                toks.append("L")
+            elif op.startswith("global_load"):
+                toks.append("l")
+            elif op == "global_store_dwordx4":
+                toks.append("S")
+            elif op == "global_store_dwordx2":
+                toks.append("s")
+            elif op.startswith("global_store"):
+                toks.append("d")
+            elif op.startswith("buffer_load"):
+                toks.append("BL")
+            elif op.startswith("buffer_store"):
+                toks.append("BS")
+            elif op.startswith("scratch_store"):
+                toks.append("xs")
+            elif op.startswith("scratch_load"):
+                toks.append("xl")
+            elif op == "s_barrier":
+                toks.append("|")
+            elif op == "s_waitcnt":
+                m = re.search(r"vmcnt\((\d+)\)", t)
+                if m:
+                    toks.append("W" + m.group(1))
+            elif op == "s_endpgm":
+                toks.append("END")
+        print("%s\n  VGPRs %s, scratch %s bytes\n  %s\n" % (name, vg, sc, " ".join(toks)))
+
+
+if __name__ == "__main__":
+    main()
