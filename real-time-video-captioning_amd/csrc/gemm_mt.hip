@@ -95,6 +95,16 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& a, const f32x4 (&
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // patch embedding: the position rows of the sub-block, requested before its first store (a load behind a store is
+    // waited for with vmcnt(0), one round trip per row; rows past valid_rows are clamped: loaded, not used)
+    f32x4 pos_v[EPI == EPI_PATCH_F32 ? 16 * NM / RPI : 1];
+    if (EPI == EPI_PATCH_F32) {
+#pragma unroll
+        for (int it = 0; it < 16 * NM / RPI; ++it) {
+            const int mc = min(mw + j0 * 16 + it * RPI + rr, a.valid_rows - 1);
+            pos_v[EPI == EPI_PATCH_F32 ? it : 0] = *(const f32x4*)(a.pos + (size_t)(1 + mc % a.patches_per_frame) * a.N + nw + rc * (16 / ESZ));
+        }
+    }
 #pragma unroll
     for (int it = 0; it < 16 * NM / RPI; ++it) {
         const int ml = it * RPI + rr;
@@ -114,7 +124,7 @@ __device__ __forceinline__ void epilogue_block(const GemmArgs& a, const f32x4 (&
                 if (m < a.valid_rows) {
                     const int frame = m / a.patches_per_frame;
                     const int patch = m - frame * a.patches_per_frame;
-                    v += *(const f32x4*)(a.pos + (size_t)(1 + patch) * a.N + n);
+                    v += pos_v[EPI == EPI_PATCH_F32 ? it : 0];
                     const size_t orow = (size_t)frame * a.tokens_per_frame + 1 + patch;
                     *(f32x4*)((float*)a.out + orow * a.ldo + n) = v;
                 }
