@@ -6,10 +6,22 @@
 #pragma once
 #include "common.h"
 
-// v (this lane's values of the row, zero beyond D) and their lane-sum s -> v = LayerNorm(row) * gamma + beta
+// this lane's NV float4 of a D-vector (columns 256 i + 4 lane).  Unconditional (a column past D reads column 0 and is not used):
+// a load under a predicate is waited for where the paths meet, i.e. at once -- callers request what a row needs as early as
+// they can, so that it is in flight behind the reductions instead of being a round trip of its own after them
 template <int NV>
-__device__ __forceinline__ void row_layernorm(f32x4 (&v)[NV], const float s, const int lane, const int D, const float eps,
-                                              const float* __restrict__ gamma, const float* __restrict__ beta) {
+__device__ __forceinline__ void row_load_vec(f32x4 (&o)[NV], const float* __restrict__ p, const int D, const int lane) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        o[i] = *(const f32x4*)(p + (c < D ? c : 0));
+    }
+}
+
+// v (this lane's values of the row, zero beyond D) and their lane-sum s -> v = LayerNorm(row) * gamma + beta (g, b: row_load_vec)
+template <int NV>
+__device__ __forceinline__ void row_layernorm_v(f32x4 (&v)[NV], const float s, const int lane, const int D, const float eps,
+                                                const f32x4 (&gv)[NV], const f32x4 (&bv)[NV]) {
 #pragma clang fp contract(off)
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
@@ -26,12 +38,19 @@ __device__ __forceinline__ void row_layernorm(f32x4 (&v)[NV], const float s, con
     for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
         if (c < D) {
-            const f32x4 g = *(const f32x4*)(gamma + c);
-            const f32x4 b = *(const f32x4*)(beta + c);
+            const f32x4 g = gv[i], b = bv[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[i][e] = __builtin_fmaf((v[i][e] - mean) * rstd, g[e], b[e]);
         }
     }
+}
+template <int NV>
+__device__ __forceinline__ void row_layernorm(f32x4 (&v)[NV], const float s, const int lane, const int D, const float eps,
+                                              const float* __restrict__ gamma, const float* __restrict__ beta) {
+    f32x4 gv[NV], bv[NV];                           // requested before the two wave reductions, used after them
+    row_load_vec<NV>(gv, gamma, D, lane);
+    row_load_vec<NV>(bv, beta, D, lane);
+    row_layernorm_v<NV>(v, s, lane, D, eps, gv, bv);
 }
 
 // t = the fixed-order sum of slabs k0 .. k0+7 of row m (missing slabs count as zero): all 8 x NV vectors are requested
@@ -53,20 +72,27 @@ __device__ __forceinline__ void row_slab_tree(f32x4 (&t)[NV], const float* __res
         t[i] = ((p[0][i] + p[1][i]) + (p[2][i] + p[3][i])) + ((p[4][i] + p[5][i]) + (p[6][i] + p[7][i]));
 }
 
-// v += bias + resid[m]; returns the lane-sum
+// v += bias + resid[m]; returns the lane-sum (bv, rv: row_load_vec of bias and of resid + m D)
 template <int NV>
-__device__ __forceinline__ float row_add_bias_resid(f32x4 (&v)[NV], const float* __restrict__ bias, const float* __restrict__ resid,
-                                                    const int D, const int m, const int lane) {
+__device__ __forceinline__ float row_add_bias_resid_v(f32x4 (&v)[NV], const f32x4 (&bv)[NV], const f32x4 (&rv)[NV], const int D, const int lane) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
         if (c < D) {
-            v[i] += *(const f32x4*)(bias + c) + *(const f32x4*)(resid + (size_t)m * D + c);
+            v[i] += bv[i] + rv[i];
             s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
         }
     }
     return s;
+}
+template <int NV>
+__device__ __forceinline__ float row_add_bias_resid(f32x4 (&v)[NV], const float* __restrict__ bias, const float* __restrict__ resid,
+                                                    const int D, const int m, const int lane) {
+    f32x4 bv[NV], rv[NV];
+    row_load_vec<NV>(bv, bias, D, lane);
+    row_load_vec<NV>(rv, resid + (size_t)m * D, D, lane);
+    return row_add_bias_resid_v<NV>(v, bv, rv, D, lane);
 }
 
 // v = sum_k slab[k][m] + bias + resid[m]; returns the lane-sum.  THE summation order of the text rows' split-K reduce:
@@ -103,12 +129,15 @@ __device__ __forceinline__ float row_load_embed_tok(f32x4 (&v)[NV], int64_t tok,
     tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);          // never index outside the table
     const float* wr = word + (size_t)tok * D;
     const float* pr = pos + (size_t)position * D;
+    f32x4 wv[NV], pv[NV];                           // both rows requested before the first add
+    row_load_vec<NV>(wv, wr, D, lane);
+    row_load_vec<NV>(pv, pr, D, lane);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
         if (c < D) {
-            v[i] = *(const f32x4*)(wr + c) + *(const f32x4*)(pr + c);
+            v[i] = wv[i] + pv[i];
             s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
         } else v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }

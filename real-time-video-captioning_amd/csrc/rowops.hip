@@ -232,6 +232,13 @@ __global__ __launch_bounds__(512) void ln_reduce_kernel(const float* __restrict_
     __shared__ __attribute__((aligned(16))) float part[7][NV * 256];           // group sums of waves 1..7
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, m = blockIdx.x;
     const int ngroups = (nslab + 7) >> 3;
+    // bias, residual row, gamma and beta of the row: requested before the slabs (every wave: a branch around the loads would be
+    // waited for where it ends), in flight behind the slab tree and the merge instead of four round trips of wave 0 after them
+    f32x4 bv[NV], rv[NV], gv[NV], bev[NV];
+    row_load_vec<NV>(bv, bias, D, lane);
+    row_load_vec<NV>(rv, resid + (size_t)m * D, D, lane);
+    row_load_vec<NV>(gv, gamma, D, lane);
+    row_load_vec<NV>(bev, beta, D, lane);
     f32x4 v[NV];
     row_slab_tree<NV>(v, slabs, nslab, g * 8, M, D, m, lane);
     if (ngroups > 1) {
@@ -246,8 +253,8 @@ __global__ __launch_bounds__(512) void ln_reduce_kernel(const float* __restrict_
             for (int i = 0; i < NV; ++i) v[i] += *(const f32x4*)(&part[j - 1][i * 256 + lane * 4]);
     }
     // (0 + t0) + t1 + ... of row_load_reduce: 0 + t0 == t0 exactly
-    const float s = row_add_bias_resid<NV>(v, bias, resid, D, m, lane);
-    row_layernorm<NV>(v, s, lane, D, eps, gamma, beta);
+    const float s = row_add_bias_resid_v<NV>(v, bv, rv, D, lane);
+    row_layernorm_v<NV>(v, s, lane, D, eps, gv, bev);
     row_store<NV>(v, lane, D, xf + (size_t)m * D, xb + (size_t)m * D);
 }
 
@@ -283,12 +290,28 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restri
     __shared__ int chosen;
     const int r = blockIdx.x, tid = threadIdx.x;
     const size_t base = (size_t)(r * row_stride + row_off) * ntiles;
+    // gamma / beta of the next step's input row do not depend on the token chosen below: requested now (wave 0 uses them)
+    f32x4 gv[NV > 0 ? NV : 1], bv[NV > 0 ? NV : 1];
+    if (NV > 0) {
+        row_load_vec<(NV > 0 ? NV : 1)>(gv, emb.gamma, emb.D, tid & 63);
+        row_load_vec<(NV > 0 ? NV : 1)>(bv, emb.beta, emb.D, tid & 63);
+    }
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < ntiles; i += 256) {
-        const float v = val[base + i];
-        const int j = idx[base + i];
-        if (v > best || (v == best && j < bi)) { best = v; bi = j; }
+    // eight partials per thread and round trip (30 522 words = 1908 tiles: one round trip instead of eight); an index past the end
+    // re-reads the last tile, which cannot change the result (max value, smallest index among equals: order does not matter)
+    for (int i0 = tid; i0 < ntiles; i0 += 256 * 8) {
+        float v8[8];
+        int j8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + 256 * u, ntiles - 1);
+            v8[u] = val[base + i];
+            j8[u] = idx[base + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v8[u] > best || (v8[u] == best && j8[u] < bi)) { best = v8[u]; bi = j8[u]; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -311,7 +334,7 @@ __global__ __launch_bounds__(256) void argmax_final_kernel(const float* __restri
         if (tid < 64) {
             f32x4 v[NV > 0 ? NV : 1];
             const float s = row_load_embed_tok<(NV > 0 ? NV : 1)>(v, (int64_t)chosen, emb.position, emb.word, emb.pos, emb.D, emb.vocab, tid);
-            row_layernorm<(NV > 0 ? NV : 1)>(v, s, tid, emb.D, emb.eps, emb.gamma, emb.beta);
+            row_layernorm_v<(NV > 0 ? NV : 1)>(v, s, tid, emb.D, emb.eps, gv, bv);
             row_store<(NV > 0 ? NV : 1)>(v, tid, emb.D, emb.xf + (size_t)r * emb.D, emb.xb + (size_t)r * emb.D);
         }
     }
