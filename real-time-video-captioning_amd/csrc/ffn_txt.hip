@@ -28,6 +28,11 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
     constexpr int NT = (D / 16) / 4;                        // FC2 output tiles (16 columns) per wave
     static_assert((D / 16) % 4 == 0, "D must be a multiple of 64");
     __shared__ __attribute__((aligned(16))) bf16_t hs[2][16][72];     // h of one m-tile (two buffers), row pitch 144 B
+    // The 16 activation rows of an m-tile, staged by LDS-DMA (two buffers): 16-byte piece c of row m sits in slot 4 K32 m + (c ^ (m & 7)).
+    // (The FC1 chain used to fetch its activation fragments from global memory: 8 requested up front, the other 16 one at a time INSIDE
+    // the chain -- there are no registers to hold them next to 192 of weight fragments -- i.e. 16 dependent round trips per launch:
+    // "L W1 L W1 ..." in tools/isa_waits.py, 6 of the launch's 9 us.  From LDS a fragment is a 64-cycle read that waits for nothing else.)
+    __shared__ __attribute__((aligned(16))) char xs[2][16 * K32 * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int frow = lane & 15, fq = lane >> 4;
@@ -77,33 +82,40 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
     float* slab = a.slabs + (size_t)s * a.M * D;
 
     const int mtiles = (a.M + 15) >> 4;
-    // 32 or more rows: the activation fragments of m-tile mt + 1 are requested before the MFMAs of m-tile mt, 8 k-steps at a
-    // time (the registers next to 192 of weight fragments)
-    constexpr int XC = K32 < 8 ? K32 : 8;
-    bf16x8 xnext[XC];
-    auto load_x = [&](int mt) {
-        int m = mt * 16 + frow;
-        m = m < a.M ? m : a.M - 1;
-        const bf16_t* xp = a.X + (size_t)m * a.ldx + fq * 8;
+    // stage m-tile mt into buffer mt & 1: 4 K32 pieces per row, 64 K32 pieces in all, 256 threads; rows past M are clamped
+    auto stage_x = [&](int mt) {
+        char* dst = xs[mt & 1];
 #pragma unroll
-        for (int k = 0; k < XC; ++k) xnext[k] = *(const bf16x8*)(xp + k * 32);
+        for (int i = 0; i < (64 * K32 + 255) / 256; ++i) {
+            const int slot = i * 256 + threadIdx.x;
+            if (64 * K32 % 256 == 0 || slot < 64 * K32) {
+                const int row = slot / (4 * K32), cs = slot - row * (4 * K32);
+                int m = mt * 16 + row;
+                m = m < a.M ? m : a.M - 1;
+                const bf16_t* src = a.X + (size_t)m * a.ldx + (cs ^ (row & 7)) * 8;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst + (i * 256 + (threadIdx.x & ~63)) * 16), 16, 0, 0);
+            }
+        }
     };
-    load_x(0);
+    stage_x(0);
     for (int mt = 0; mt < mtiles; ++mt) {
         int m = mt * 16 + frow;
         const bool mvalid = m < a.M;
         m = mvalid ? m : a.M - 1;                            // clamp: padded rows are discarded
+        // the tile's rows (and, the first time, every weight fragment) have landed; everyone is past the previous tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         // ---- FC1 + GELU: h[m][nh .. nh + 3] -> LDS (bf16) ----
-        const bf16_t* xp = a.X + (size_t)m * a.ldx + fq * 8;
+        const char* xb = xs[mt & 1] + frow * (64 * K32);
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < XC; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[k], xnext[k], acc, 0, 0, 0);
-#pragma unroll
-        for (int k = XC; k < K32; ++k) {
-            const bf16x8 xf = *(const bf16x8*)(xp + k * 32);
+        for (int k = 0; k < K32; ++k) {
+            const bf16x8 xf = *(const bf16x8*)(xb + (((k * 4 + fq) ^ (frow & 7)) << 4));
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[k], xf, acc, 0, 0, 0);
         }
-        if (mt + 1 < mtiles) load_x(mt + 1);
+        // the next tile's rows: in flight under GELU, FC2 and the stores (its buffer was last read in tile mt - 1; every wave is past
+        // the barrier above).  Behind the LDS reads of this tile: in front of them the compiler would wait for it at once
+        if (mt + 1 < mtiles) stage_x(mt + 1);
         uint2 hv;
         hv.x = pack_bf2(erf_gelu(acc[0] + bias[0]), erf_gelu(acc[1] + bias[1]));
         hv.y = pack_bf2(erf_gelu(acc[2] + bias[2]), erf_gelu(acc[3] + bias[3]));
