@@ -383,6 +383,7 @@ __global__ __launch_bounds__(NW * 64, 4) void txt_block_kernel(TxtBlockArgs a) {
             v[c] = 0.f; g[c] = 0.f; b[c] = 0.f;
             if (act[c]) {
                 g[c] = a.g1[col]; b[c] = a.b1[col];
+                const float ab = a.aob[col], xi = a.xin[(size_t)m * D + col];     // requested with gamma / beta, ahead of the partials
                 // all H partials are requested before the first add; summed in head order
                 float s = 0.f;
                 const float* pp = a.part + (size_t)m * H * D + col;
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(NW * 64, 4) void txt_block_kernel(TxtBlockArgs a) {
 #pragma unroll
                     for (int h = 0; h < 12; ++h) s += p[h];
                 }
-                v[c] = s + (a.aob[col] + a.xin[(size_t)m * D + col]);
+                v[c] = s + (ab + xi);
             }
         }
         block_layernorm<NC>(v, act, D, a.eps, g, b, red, tid);
