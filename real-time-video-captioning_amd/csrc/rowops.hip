@@ -426,11 +426,21 @@ __global__ __launch_bounds__(64) void beam_topk_merge_kernel(const float2* __res
                                                              int* __restrict__ out_idx) {
     __shared__ float add[16];
     const int b = blockIdx.x, lane = threadIdx.x;
-    for (int j = 0; j < beams; ++j) {                                    // log-sum-exp of row j from its chunks (nch <= 64)
-        const float2 st = lane < nch ? stats[(size_t)(b * beams + j) * nch + lane] : float2{-INFINITY, 0.f};
+    // (the chunk statistics of four beams per round trip, the candidates eight per round trip: requested together, then used --
+    // one at a time every load was a round trip of its own, 30 of them for 4 beams x 30 chunks x 8 candidates)
+    for (int j0 = 0; j0 < beams; j0 += 4) {
+        float2 st4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) st4[u] = stats[(size_t)(b * beams + min(j0 + u, beams - 1)) * nch + min(lane, nch - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u;
+        if (j >= beams) break;
+        const float2 st = lane < nch ? st4[u] : float2{-INFINITY, 0.f};  // log-sum-exp of row j from its chunks (nch <= 64)
         const float M = wave_max(st.x);
         const float S = wave_sum(st.y == 0.f ? 0.f : st.y * expf(st.x - M));
         if (lane == 0) add[j] = beam_scores[b * beams + j] - (M + logf(S));
+        }
     }
     __syncthreads();
     float tv[KMAX];
@@ -438,16 +448,26 @@ __global__ __launch_bounds__(64) void beam_topk_merge_kernel(const float2* __res
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) { tv[k] = -INFINITY; ti[k] = 0x7fffffff; }
     const int per_row = nch * K, total = beams * per_row;
-    for (int t = lane; t < total; t += 64) {
-        const int j = t / per_row;
-        const size_t at = (size_t)(b * beams) * per_row + t;
-        const int ci = cidx[at];
-        if (ci == 0x7fffffff) continue;                                  // an empty slot of a short last chunk
-        float v = cval[at] + add[j];
-        int id = j * V + ci;
+    for (int t0 = lane; t0 < total; t0 += 64 * 8) {
+        int ci8[8];
+        float cv8[8];
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-            if (v > tv[k] || (v == tv[k] && id < ti[k])) { const float fv = tv[k]; const int fi = ti[k]; tv[k] = v; ti[k] = id; v = fv; id = fi; }
+        for (int u = 0; u < 8; ++u) {
+            const size_t at = (size_t)(b * beams) * per_row + min(t0 + 64 * u, total - 1);
+            ci8[u] = cidx[at];
+            cv8[u] = cval[at];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + 64 * u;
+            if (t >= total || ci8[u] == 0x7fffffff) continue;            // past the end / an empty slot of a short last chunk
+            const int j = t / per_row;
+            float v = cv8[u] + add[j];
+            int id = j * V + ci8[u];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (v > tv[k] || (v == tv[k] && id < ti[k])) { const float fv = tv[k]; const int fi = ti[k]; tv[k] = v; ti[k] = id; v = fv; id = fi; }
+        }
     }
     for (int k = 0; k < K; ++k) {                                        // K rounds of wave arg-max over the list heads
         float bv = tv[0];
