@@ -102,6 +102,9 @@ template <int NV>
 __device__ __forceinline__ float row_load_reduce(f32x4 (&v)[NV], const float* __restrict__ slabs, const int nslab,
                                                  const float* __restrict__ bias, const float* __restrict__ resid,
                                                  const int M, const int D, const int m, const int lane) {
+    f32x4 bv[NV], rv[NV];                           // bias and the residual row: requested before the slabs, used after them
+    row_load_vec<NV>(bv, bias, D, lane);
+    row_load_vec<NV>(rv, resid + (size_t)m * D, D, lane);
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     int k0 = 0;
@@ -119,7 +122,7 @@ __device__ __forceinline__ float row_load_reduce(f32x4 (&v)[NV], const float* __
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] += t[i];
     }
-    return row_add_bias_resid<NV>(v, bias, resid, D, m, lane);
+    return row_add_bias_resid_v<NV>(v, bv, rv, D, lane);
 }
 
 // v = word[tok] + pos[position]; returns the lane-sum

@@ -79,10 +79,12 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
         constexpr int NV = (K32 * 32 + 255) / 256;
         const SkinnyArgs::RowPrologue& p = a.ln;
         for (int m = 0; m < a.M; ++m) {
-            f32x4 v[NV];
+            f32x4 v[NV], gv[NV], bev[NV];
+            row_load_vec<NV>(gv, p.g, a.K, lane);                // gamma / beta: requested ahead of the row's own loads
+            row_load_vec<NV>(bev, p.b, a.K, lane);
             const float s = p.kind == 1 ? row_load_reduce<NV>(v, p.slabs, p.nslab, p.bias, p.resid, a.M, a.K, m, lane)
                                         : row_load_embed<NV>(v, p.ids, p.ld_ids, p.T, p.t0, p.word, p.pos, a.K, p.vocab, m, lane);
-            row_layernorm<NV>(v, s, lane, a.K, p.eps, p.g, p.b);
+            row_layernorm_v<NV>(v, s, lane, a.K, p.eps, gv, bev);
             row_store<NV>(v, lane, a.K, blockIdx.x == 0 ? p.xf + (size_t)m * a.K : nullptr, (bf16_t*)nullptr);
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
