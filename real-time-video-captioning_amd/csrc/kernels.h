@@ -89,6 +89,9 @@ struct SkinnyArgs {
     int ksplit;                            // splitk: number of K slabs (0: skinny_ksplit(K))
 };
 extern std::atomic<bool> g_row_prologue;                                 // gitcap.hip: GITCAP_NO_ROW_PROLOGUE / gitcap_dbg_config(1, .)
+// vocabulary head: four 16-column tiles per workgroup share the activation rows through LDS (skinny.hip: skinny_head_kernel);
+// GITCAP_NO_HEAD_SHARE / gitcap_dbg_config(10, 0): one single-wave workgroup per tile.  Same bits either way.
+extern std::atomic<bool> g_head_share;
 bool skinny_row_prologue_ok(int M, int K, bool fp8);         // shapes the row-prologue form is instantiated for
 hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s);
 bool skinny_full_ok(int K);                                  // K depths launch_skinny is instantiated for

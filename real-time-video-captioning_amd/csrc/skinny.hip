@@ -67,6 +67,34 @@ __device__ __forceinline__ void load_wfrags(const void* W, const void* Wpk, cons
     }
 }
 
+// fp32 logits of one 16 x 16 tile (lane: out[m][n .. n+3]) and the tile's arg-max partial per row (ascending n: first max wins)
+__device__ __forceinline__ void logits_epilogue(const SkinnyArgs& a, const float (&y)[4], const int m, const bool mvalid, const int n,
+                                                const int fq, const int tile, const int ntiles) {
+    if (mvalid && a.out) {
+        float* op = (float*)a.out + (size_t)m * a.ldo + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < a.N) op[r] = y[r];
+    }
+    if (a.amax_val) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < a.N && (y[r] > best)) { best = y[r]; bi = n + r; }
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) {
+            const float v2 = __shfl_xor(best, off);
+            const int i2 = __shfl_xor(bi, off);
+            if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+        }
+        if (fq == 0 && mvalid) {
+            a.amax_val[(size_t)m * ntiles + tile] = best;
+            a.amax_idx[(size_t)m * ntiles + tile] = bi;
+        }
+    }
+}
+
 template <int K32, int EPI, bool FP8, bool LNR>
 __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
     const int lane = threadIdx.x;
@@ -162,30 +190,72 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
                 }
             }
         } else {  // SK_BIAS_F32: logits (+ arg-max partial of this 16-column tile)
-            if (mvalid && a.out) {
-                float* op = (float*)a.out + (size_t)m * a.ldo + n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < a.N) op[r] = y[r];
-            }
-            if (a.amax_val) {
-                float best = -INFINITY;
-                int bi = 0x7fffffff;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < a.N && (y[r] > best)) { best = y[r]; bi = n + r; }   // ascending n: first max wins
-#pragma unroll
-                for (int off = 16; off < 64; off <<= 1) {
-                    const float v2 = __shfl_xor(best, off);
-                    const int i2 = __shfl_xor(bi, off);
-                    if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
-                }
-                if (fq == 0 && mvalid) {
-                    a.amax_val[(size_t)m * gridDim.x + blockIdx.x] = best;
-                    a.amax_idx[(size_t)m * gridDim.x + blockIdx.x] = bi;
-                }
-            }
+            logits_epilogue(a, y, m, mvalid, n, fq, blockIdx.x, gridDim.x);
         }
+    }
+}
+
+// ---- vocabulary head with shared activation rows ------------------------------------------------------------------------
+// skinny_full with SK_BIAS_F32 runs one single-wave workgroup per 16-column tile and every one of them fetches the same
+// 16 x K activation tile -- at K = 768 as many bytes as the weight tile it owns, 1908 times over for the 30522-word
+// vocabulary (through L2, but through the CU's one vector-memory port all the same).  Here four waves = four neighbouring
+// tiles form a workgroup that fetches the activation m-tile ONCE, into LDS (row pitch + 16 B: the 16 lanes of a
+// ds_read_b128 group fall into 16 different 16-byte slots), requested ahead of the weight fragments so that the LDS copy
+// waits for it alone (vmcnt counts in order) while the weights stay in flight; m-tile mt + 1 is in flight under m-tile mt
+// (two LDS images).  Every output element is the same MFMA chain over the same operands as in skinny_full: same bits.
+template <int K32, bool FP8>
+__global__ __launch_bounds__(256) void skinny_head_kernel(SkinnyArgs a, const int ntiles) {
+    static_assert(K32 % 4 == 0, "16 x K32 x 4 16-byte pieces over 256 threads");
+    constexpr int PITCH = K32 * 64 + 16, CPR = K32 * 4, NC = K32 / 4;
+    __shared__ __attribute__((aligned(16))) char xs[2][16 * PITCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int tile_raw = blockIdx.x * 4 + wave;
+    const bool active = tile_raw < ntiles;                       // the last workgroup may hold fewer than four tiles: such a
+    const int tile = active ? tile_raw : ntiles - 1;             // wave repeats the last tile and stores nothing
+    const int n0 = tile * 16;
+    const int mtiles = (a.M + 15) >> 4;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 st[NC];
+    auto gload = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = (int)threadIdx.x + 256 * i, row = c / CPR, col = c - row * CPR;
+            int m = mt * 16 + row;
+            m = m < a.M ? m : a.M - 1;                           // clamp: padded rows are discarded
+            st[i] = *(const u32x4*)(a.X + (size_t)m * a.ldx + col * 8);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int c = (int)threadIdx.x + 256 * i, row = c / CPR, col = c - row * CPR;
+            *(u32x4*)(&xs[buf][row * PITCH + col * 16]) = st[i];
+        }
+    };
+    gload(0);
+    bf16x8 wf[K32];
+    load_wfrags<K32, FP8>(a.W, a.Wpk, a.wscale, (size_t)(n0 + frow), a.K, fq * 8, wf);
+    const int n = n0 + fq * 4;
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = (a.bias && n + r < a.N) ? a.bias[n + r] : 0.f;
+    lstore(0);
+    __syncthreads();
+    for (int mt = 0; mt < mtiles; ++mt) {
+        if (mt + 1 < mtiles) gload(mt + 1);
+        const char* xb = &xs[mt & 1][frow * PITCH + fq * 16];
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < K32; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k], *(const bf16x8*)(xb + k * 64), acc, 0, 0, 0);
+        const int m = mt * 16 + frow;
+        const bool mvalid = m < a.M && active;
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = acc[r] + bias[r];
+        logits_epilogue(a, y, m < a.M ? m : a.M - 1, mvalid, n, fq, tile, ntiles);
+        if (mt + 1 < mtiles) lstore((mt + 1) & 1);              // the image m-tile mt - 1 was read from: every wave is past the
+        __syncthreads();                                         // barrier that closed that iteration
     }
 }
 
@@ -229,6 +299,13 @@ template <int K32, bool FP8>
 hipError_t launch_full(const SkinnyArgs& a, int epi, hipStream_t s) {
     const int grid = (a.N + 15) / 16;
     if (a.ln.kind) return hipErrorInvalidValue;          // row prologue: launch_full_rows
+    if constexpr (K32 % 4 == 0 && K32 * 64 * 32 + 512 <= 64 * 1024) {
+        // the vocabulary head (many tiles over few rows): four tiles per workgroup share the activation rows through LDS
+        if (epi == SK_BIAS_F32 && g_head_share && grid >= 64 && a.ldx % 8 == 0 && ((uintptr_t)a.X & 15) == 0) {
+            hipLaunchKernelGGL((skinny_head_kernel<K32, FP8>), dim3((grid + 3) / 4), dim3(256), 0, s, a, grid);
+            return hipGetLastError();
+        }
+    }
     switch (epi) {
         case SK_BIAS_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16, FP8, false>), dim3(grid), dim3(64), 0, s, a); break;
         case SK_BIAS_GELU_BF16: hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_GELU_BF16, FP8, false>), dim3(grid), dim3(64), 0, s, a); break;
