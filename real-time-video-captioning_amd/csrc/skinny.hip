@@ -205,8 +205,7 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
 // (two LDS images).  Every output element is the same MFMA chain over the same operands as in skinny_full: same bits.
 template <int K32, bool FP8>
 __global__ __launch_bounds__(256) void skinny_head_kernel(SkinnyArgs a, const int ntiles) {
-    static_assert(K32 % 4 == 0, "16 x K32 x 4 16-byte pieces over 256 threads");
-    constexpr int PITCH = K32 * 64 + 16, CPR = K32 * 4, NC = K32 / 4;
+    constexpr int PITCH = K32 * 64 + 16, CPR = K32 * 4, NC = (16 * CPR + 255) / 256;     // 16 x CPR 16-byte pieces over 256 threads
     __shared__ __attribute__((aligned(16))) char xs[2][16 * PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frow = lane & 15, fq = lane >> 4;
@@ -220,7 +219,8 @@ __global__ __launch_bounds__(256) void skinny_head_kernel(SkinnyArgs a, const in
     auto gload = [&](int mt) {
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-            const int c = (int)threadIdx.x + 256 * i, row = c / CPR, col = c - row * CPR;
+            const int c0 = (int)threadIdx.x + 256 * i, c = c0 < 16 * CPR ? c0 : 0;      // (K = 576: 4.5 pieces per thread)
+            const int row = c / CPR, col = c - row * CPR;
             int m = mt * 16 + row;
             m = m < a.M ? m : a.M - 1;                           // clamp: padded rows are discarded
             st[i] = *(const u32x4*)(a.X + (size_t)m * a.ldx + col * 8);
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void skinny_head_kernel(SkinnyArgs a, const in
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const int c = (int)threadIdx.x + 256 * i, row = c / CPR, col = c - row * CPR;
-            *(u32x4*)(&xs[buf][row * PITCH + col * 16]) = st[i];
+            if (c < 16 * CPR) *(u32x4*)(&xs[buf][row * PITCH + col * 16]) = st[i];
         }
     };
     gload(0);
@@ -299,9 +299,9 @@ template <int K32, bool FP8>
 hipError_t launch_full(const SkinnyArgs& a, int epi, hipStream_t s) {
     const int grid = (a.N + 15) / 16;
     if (a.ln.kind) return hipErrorInvalidValue;          // row prologue: launch_full_rows
-    if constexpr (K32 % 4 == 0 && K32 * 64 * 32 + 512 <= 64 * 1024) {
+    if constexpr (K32 * 64 * 32 + 512 <= 64 * 1024) {          // two LDS images of 16 rows (K <= 768)
         // the vocabulary head (many tiles over few rows): four tiles per workgroup share the activation rows through LDS
-        if (epi == SK_BIAS_F32 && g_head_share && grid >= 64 && a.ldx % 8 == 0 && ((uintptr_t)a.X & 15) == 0) {
+        if (epi == SK_BIAS_F32 && g_head_share && grid >= 4 && a.ldx % 8 == 0 && ((uintptr_t)a.X & 15) == 0) {
             hipLaunchKernelGGL((skinny_head_kernel<K32, FP8>), dim3((grid + 3) / 4), dim3(256), 0, s, a, grid);
             return hipGetLastError();
         }

@@ -156,7 +156,7 @@ struct gitcap_student {
     // ids / steps buffers, which are copied to the caller's after the replay
     int64_t* g_ids = nullptr;
     int32_t* g_steps = nullptr;
-    struct GreedyGraph { int B, max_len, stop; bool rows_pro; hipGraphExec_t exec; };
+    struct GreedyGraph { int B, max_len, stop; bool rows_pro, head_share; hipGraphExec_t exec; };
     std::vector<GreedyGraph> graphs;
     hipStream_t cap_stream = nullptr;   // capture only (the legacy default stream cannot be captured); replays run on the caller's stream
     // device-resident beam search (gitcap_student_beam_search), allocated on first use
@@ -497,7 +497,7 @@ int gitcap_student_greedy(gitcap_student_t* h, const float* memory, int B, int m
     if (use_graph) {
         hipGraphExec_t exec = nullptr;
         for (auto& g : h->graphs)
-            if (g.B == B && g.max_len == max_len && g.stop == stop && g.rows_pro == g_row_prologue) exec = g.exec;
+            if (g.B == B && g.max_len == max_len && g.stop == stop && g.rows_pro == g_row_prologue && g.head_share == g_head_share) exec = g.exec;
         if (!exec) {
             hipGraph_t graph = nullptr;
             if (!h->cap_stream) S_HIP_OK(h, hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
@@ -509,7 +509,7 @@ int gitcap_student_greedy(gitcap_student_t* h, const float* memory, int B, int m
             e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             S_HIP_OK(h, e);
-            h->graphs.push_back({B, max_len, stop, g_row_prologue, exec});
+            h->graphs.push_back({B, max_len, stop, g_row_prologue, g_head_share, exec});
         }
         S_HIP_OK(h, hipGraphLaunch(exec, s));
     } else if ((rc = enqueue_loop(s))) {

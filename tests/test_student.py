@@ -290,3 +290,9 @@ def test_gpu_student_row_prologue_switch_changes_nothing(name):
         lib.gitcap_dbg_config(1, old)
     for a, b, n in zip(on, off, (1, 2)):
         assert torch.equal(a, b) and torch.equal(a, full[:n])
+    # key 10: the vocabulary head as one single-wave workgroup per 16-column tile instead of four tiles sharing the rows in LDS
+    old = lib.gitcap_dbg_config(10, 0)
+    try:
+        assert torch.equal(m.greedy_decode(mem, max_len=16, stop="never"), full)
+    finally:
+        lib.gitcap_dbg_config(10, old)
