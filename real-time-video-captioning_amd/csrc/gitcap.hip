@@ -26,6 +26,7 @@
 // g_row_prologue is shared with student.hip.
 std::atomic<bool> g_row_prologue{!env_flag("GITCAP_NO_ROW_PROLOGUE")};
 std::atomic<bool> g_head_share{!env_flag("GITCAP_NO_HEAD_SHARE")};        // kernels.h; gitcap_dbg_config(10, .)
+std::atomic<bool> g_rows3{!env_flag("GITCAP_NO_ROWS3")};                  // kernels.h; gitcap_dbg_config(11, .)
 
 // compute units of the current device, cached per device (the workgroup -> tile maps and the tile-height choice depend on it)
 int device_cus() {
@@ -1373,6 +1374,7 @@ int gitcap_dbg_config(int key, int value) {
         case 8: old = g_wpack.exchange(value != 0); break;
         case 9: old = g_txt8.exchange(value != 0); break;
         case 10: old = g_head_share.exchange(value != 0); break;
+        case 11: old = g_rows3.exchange(value != 0); break;
         default: return GITCAP_ERR_ARG;
     }
     return old;

@@ -92,6 +92,9 @@ extern std::atomic<bool> g_row_prologue;                                 // gitc
 // vocabulary head: four 16-column tiles per workgroup share the activation rows through LDS (skinny.hip: skinny_head_kernel);
 // GITCAP_NO_HEAD_SHARE / gitcap_dbg_config(10, 0): one single-wave workgroup per tile.  Same bits either way.
 extern std::atomic<bool> g_head_share;
+// one/two-row prologue over more than 16 slabs: three-wave workgroups that share the reduce (skinny.hip: skinny_rows3_kernel);
+// GITCAP_NO_ROWS3 / gitcap_dbg_config(11, 0): the single-wave form.  Same bits either way.
+extern std::atomic<bool> g_rows3;
 bool skinny_row_prologue_ok(int M, int K, bool fp8);         // shapes the row-prologue form is instantiated for
 hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s);
 bool skinny_full_ok(int K);                                  // K depths launch_skinny is instantiated for

@@ -259,6 +259,107 @@ __global__ __launch_bounds__(256) void skinny_head_kernel(SkinnyArgs a, const in
     }
 }
 
+// ---- one/two-row prologue over many slabs: three waves share the reduce ---------------------------------------------------
+// The fused FFN launch (ffn_txt.hip) leaves dec_ffn / 64 = 48 slabs; the single wave of skinny_full<LNR> walks them in three
+// dependent round trips (two 8-slab groups each) before it can normalise its row -- in every one of the 144 workgroups, 150
+// times per single-clip caption.  Here a workgroup is three waves = three neighbouring 16-column tiles: wave w sums groups
+// 2w and 2w + 1 of the row (one round trip, side by side), waves 1 and 2 hand their group sums over through LDS, wave 0 adds
+// them in the canonical order (rowln.h: 0 + t0 + t1 + ... ascending; the same adds as row_load_reduce and ln_reduce_kernel),
+// adds bias + residual, normalises and leaves the bf16 row in LDS; then every wave runs its own tile's MFMA chain.  Same bits.
+template <int K32, int EPI>
+__global__ __launch_bounds__(192) void skinny_rows3_kernel(SkinnyArgs a) {
+    constexpr int NV = (K32 * 32 + 255) / 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int ntiles = (a.N + 15) / 16;
+    const int tile_raw = blockIdx.x * 3 + wave;
+    const bool active = tile_raw < ntiles;                       // (a wave past the last tile repeats it and stores nothing)
+    const int n0 = (active ? tile_raw : ntiles - 1) * 16;
+    bf16x8 wf[K32];
+    load_wfrags<K32, false>(a.W, a.Wpk, a.wscale, (size_t)(n0 + frow), a.K, fq * 8, wf);
+    __shared__ __attribute__((aligned(16))) bf16_t xrow[2][K32 * 32];
+    __shared__ __attribute__((aligned(16))) float part[2][2][NV * 256];        // group sums of waves 1, 2
+    const SkinnyArgs::RowPrologue& p = a.ln;
+    const int ngroups = (p.nslab + 7) >> 3;
+    for (int m = 0; m < a.M; ++m) {
+        // what wave 0 needs after the merge: requested by every wave ahead of the slabs (a branch around loads is waited for where
+        // it ends), in flight behind the trees
+        f32x4 bv[NV], rv[NV], gv[NV], bev[NV];
+        row_load_vec<NV>(bv, p.bias, a.K, lane);
+        row_load_vec<NV>(rv, p.resid + (size_t)m * a.K, a.K, lane);
+        row_load_vec<NV>(gv, p.g, a.K, lane);
+        row_load_vec<NV>(bev, p.b, a.K, lane);
+        f32x4 ta[NV], tb[NV];
+        row_slab_tree<NV>(ta, p.slabs, p.nslab, wave * 16, a.M, a.K, m, lane);
+        row_slab_tree<NV>(tb, p.slabs, p.nslab, wave * 16 + 8, a.M, a.K, m, lane);
+        if (wave > 0) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                *(f32x4*)(&part[wave - 1][0][i * 256 + lane * 4]) = ta[i];
+                *(f32x4*)(&part[wave - 1][1][i * 256 + lane * 4]) = tb[i];
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            f32x4 v[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) { v[i] = f32x4{0.f, 0.f, 0.f, 0.f}; v[i] += ta[i]; }
+            if (ngroups > 1) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) v[i] += tb[i];
+            }
+            for (int g = 2; g < ngroups; ++g)
+#pragma unroll
+                for (int i = 0; i < NV; ++i) v[i] += *(const f32x4*)(&part[(g >> 1) - 1][g & 1][i * 256 + lane * 4]);
+            const float s = row_add_bias_resid_v<NV>(v, bv, rv, a.K, lane);
+            row_layernorm_v<NV>(v, s, lane, a.K, p.eps, gv, bev);
+            row_store<NV>(v, lane, a.K, blockIdx.x == 0 ? p.xf + (size_t)m * a.K : nullptr, (bf16_t*)nullptr);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = i * 256 + lane * 4;
+                if (c < K32 * 32) {
+                    uint2 o;
+                    o.x = pack_bf2(v[i][0], v[i][1]);
+                    o.y = pack_bf2(v[i][2], v[i][3]);
+                    *(uint2*)(&xrow[m][c]) = o;
+                }
+            }
+        }
+        __syncthreads();                                        // the row is in LDS; `part` may be overwritten
+    }
+    const int n = n0 + fq * 4;
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = (a.bias && n + r < a.N) ? a.bias[n + r] : 0.f;
+    int m = frow;
+    const bool mvalid = m < a.M && active;
+    m = m < a.M ? m : a.M - 1;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < K32; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k], *(const bf16x8*)(&xrow[m][fq * 8 + k * 32]), acc, 0, 0, 0);
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = acc[r] + bias[r];
+    if (EPI == SK_BIAS_RELU_BF16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r] = fmaxf(y[r], 0.f);
+    }
+    if (mvalid) {
+        const int orow = (m / a.T) * a.row_stride + a.row_off + (m % a.T);
+        bf16_t* op = (bf16_t*)a.out + (size_t)orow * a.ldo + n;
+        if (n + 3 < a.N) {
+            uint2 v;
+            v.x = pack_bf2(y[0], y[1]);
+            v.y = pack_bf2(y[2], y[3]);
+            *(uint2*)op = v;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < a.N) op[r] = f2bf(y[r]);
+        }
+    }
+}
+
 // grid = (n_tiles, ksplit); slab[ks][m][n] fp32 partial sums (no bias)
 template <int K32, bool FP8>
 __global__ __launch_bounds__(64) void skinny_splitk_kernel(SkinnyArgs a) {
@@ -325,6 +426,14 @@ hipError_t launch_full_rows(const SkinnyArgs& a, int epi, hipStream_t s) {
         (p.kind == 2 && (!p.ids || p.T <= 0 || !p.word || !p.pos)) || (p.kind != 1 && p.kind != 2))
         return hipErrorInvalidValue;
     const dim3 grid((a.N + 15) / 16);
+    // many slabs (the fused FFN's 48): three waves per workgroup share the reduce (skinny_rows3_kernel)
+    if (g_rows3 && p.kind == 1 && p.nslab > 16 && p.nslab <= 48) {
+        const dim3 grid3((grid.x + 2) / 3);
+        if (epi == SK_BIAS_BF16) hipLaunchKernelGGL((skinny_rows3_kernel<K32, SK_BIAS_BF16>), grid3, dim3(192), 0, s, a);
+        else if (epi == SK_BIAS_RELU_BF16) hipLaunchKernelGGL((skinny_rows3_kernel<K32, SK_BIAS_RELU_BF16>), grid3, dim3(192), 0, s, a);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (epi == SK_BIAS_BF16) hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16, false, true>), grid, dim3(64), 0, s, a);
     else if (epi == SK_BIAS_RELU_BF16) hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_RELU_BF16, false, true>), grid, dim3(64), 0, s, a);
     else return hipErrorInvalidValue;
