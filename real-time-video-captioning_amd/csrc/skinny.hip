@@ -11,6 +11,9 @@
 //
 //   skinny_full  : whole K per wave, fused epilogue (bias [+GELU] -> bf16, or fp32 logits + a
 //                  per-tile arg-max partial for the vocabulary head).
+//   skinny_head  : the vocabulary head (SK_BIAS_F32 over many tiles): four tiles per workgroup share the activation m-tile
+//                  through LDS instead of fetching it once per tile (round 4; same MFMA chain, same bits).
+//   skinny_rows3 : the row-prologue form over the fused FFN's 48 slabs: three waves share the slab reduce (round 4).
 //   skinny_splitk: K split over blocks (more waves in flight for the K=3072 matrix and for the
 //                  N=768 ones that would otherwise use 48 waves); each wave writes its fp32
 //                  partial tile to a slab; ln_reduce_kernel (rowops.hip) sums the slabs in a fixed
