@@ -19,6 +19,7 @@
 // launch_skinny(SK_BIAS_GELU_BF16) followed by launch_skinny_splitk(ksplit = F / 64): the same MFMA sequence per
 // element (tests/test_kernels_gpu.py; GITCAP_NO_FFN_FUSE / gitcap_dbg_config(7, 0) selects that pair of launches).
 #include "kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -38,6 +39,28 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
     const int frow = lane & 15, fq = lane >> 4;
     const int s = blockIdx.x;
     const int F32 = a.F >> 5;
+
+    const int mtiles = (a.M + 15) >> 4;
+    // m-tile mt -> registers -> LDS buffer mt & 1: 4 K32 16-byte pieces per row, 64 K32 in all, 256 threads; rows past M are clamped.
+    // (Round 4 first staged by LDS-DMA.  With DMA in the kernel the compiler stops counting: it waits with vmcnt(0) in front of every LDS
+    // access that follows a DMA request -- and on gfx9 vmcnt counts stores -- so every further m-tile cost a DMA round trip plus the drain
+    // of the previous tile's 12 slab stores: 32 rows 11.0 us against 7.2 for 16; tools/isa_waits.py: [ W0 | D x 6 W0 | S x 12.  Plain
+    // loads are counted: the rows of tile mt + 1 are requested behind the FC1 reads of tile mt and written to LDS behind its stores,
+    // waiting for "all but the NT stores".)
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    constexpr int NP = (64 * K32 + 255) / 256;
+    u32x4 st[NP];
+    auto gload_x = [&](int mt) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int slot0 = i * 256 + (int)threadIdx.x, slot = (64 * K32 % 256 == 0 || slot0 < 64 * K32) ? slot0 : 0;
+            const int row = slot / (4 * K32), cs = slot - row * (4 * K32);
+            int m = mt * 16 + row;
+            m = m < a.M ? m : a.M - 1;
+            st[i] = *(const u32x4*)(a.X + (size_t)m * a.ldx + (cs ^ (row & 7)) * 8);
+        }
+    };
+    gload_x(0);                                             // ahead of the weights: the LDS copy below waits for these alone
 
     // ---- every weight fragment of the wave, requested back to back: 16 hidden rows of W1 (K32 k-steps), then the two
     //      k-steps (hidden 64 s .. + 63) of its NT column tiles of W2
@@ -81,30 +104,27 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
     for (int r = 0; r < 4; ++r) bias[r] = a.b1[nh + r];
     float* slab = a.slabs + (size_t)s * a.M * D;
 
-    const int mtiles = (a.M + 15) >> 4;
-    // stage m-tile mt into buffer mt & 1: 4 K32 pieces per row, 64 K32 pieces in all, 256 threads; rows past M are clamped
-    auto stage_x = [&](int mt) {
+    auto lstore_x = [&](int mt) {
         char* dst = xs[mt & 1];
 #pragma unroll
-        for (int i = 0; i < (64 * K32 + 255) / 256; ++i) {
-            const int slot = i * 256 + threadIdx.x;
-            if (64 * K32 % 256 == 0 || slot < 64 * K32) {
-                const int row = slot / (4 * K32), cs = slot - row * (4 * K32);
-                int m = mt * 16 + row;
-                m = m < a.M ? m : a.M - 1;
-                const bf16_t* src = a.X + (size_t)m * a.ldx + (cs ^ (row & 7)) * 8;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst + (i * 256 + (threadIdx.x & ~63)) * 16), 16, 0, 0);
-            }
+        for (int i = 0; i < NP; ++i) {
+            const int slot = i * 256 + (int)threadIdx.x;
+            if (64 * K32 % 256 == 0 || slot < 64 * K32) *(u32x4*)(dst + slot * 16) = st[i];
         }
     };
-    stage_x(0);
-    for (int mt = 0; mt < mtiles; ++mt) {
+    __builtin_amdgcn_sched_barrier(0);                      // not in front of the weight requests (the copy waits for the rows)
+    lstore_x(0);
+    // PREFETCH (launches of several m-tiles): the next tile's rows are requested and copied UNCONDITIONALLY (the last tile re-reads
+    // itself): a load under a branch is waited for where the branch ends, i.e. at once
+    auto do_tile = [&](const int mt, auto prefetch_c) {
+        constexpr bool PREFETCH = decltype(prefetch_c)::value;
         int m = mt * 16 + frow;
-        const bool mvalid = m < a.M;
-        m = mvalid ? m : a.M - 1;                            // clamp: padded rows are discarded
-        // the tile's rows (and, the first time, every weight fragment) have landed; everyone is past the previous tile
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        m = m < a.M ? m : a.M - 1;                           // clamp: a padded row repeats row M - 1
+        // the tile's rows are in LDS (this wave's pieces: lgkmcnt; everyone's: the barrier); everyone is past the previous tile.
+        // Bare s_barrier: __syncthreads() is a fence too, and for the fence the compiler waits with vmcnt(0), i.e. for the slab stores
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         // ---- FC1 + GELU: h[m][nh .. nh + 3] -> LDS (bf16) ----
         const char* xb = xs[mt & 1] + frow * (64 * K32);
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -113,9 +133,8 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
             const bf16x8 xf = *(const bf16x8*)(xb + (((k * 4 + fq) ^ (frow & 7)) << 4));
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[k], xf, acc, 0, 0, 0);
         }
-        // the next tile's rows: in flight under GELU, FC2 and the stores (its buffer was last read in tile mt - 1; every wave is past
-        // the barrier above).  Behind the LDS reads of this tile: in front of them the compiler would wait for it at once
-        if (mt + 1 < mtiles) stage_x(mt + 1);
+        // the next tile's rows: in flight under GELU, FC2 and the stores
+        if (PREFETCH) gload_x(mt + 1 < mtiles ? mt + 1 : mt);
         uint2 hv;
         hv.x = pack_bf2(erf_gelu(acc[0] + bias[0]), erf_gelu(acc[1] + bias[1]));
         hv.y = pack_bf2(erf_gelu(acc[2] + bias[2]), erf_gelu(acc[3] + bias[3]));
@@ -123,7 +142,9 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
         *(uint2*)(&hb[frow][wave * 16 + fq * 4]) = hv;
         // one barrier per m-tile: buffer (mt + 1) & 1 is rewritten only after every wave has passed this barrier, i.e. after
         // it finished reading that buffer in iteration mt - 1
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this wave's h values are in LDS
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         // ---- FC2 share of the slice: out[m][n] for the wave's NT tiles ----
         const bf16x8 h0 = *(const bf16x8*)(&hb[frow][fq * 8]), h1 = *(const bf16x8*)(&hb[frow][32 + fq * 8]);
 #pragma unroll
@@ -131,8 +152,18 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
             f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
             o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[t][0], h0, o, 0, 0, 0);
             o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[t][1], h1, o, 0, 0, 0);
-            if (mvalid) *(f32x4*)(slab + (size_t)m * D + (wave * NT + t) * 16 + fq * 4) = o;
+            // unconditional: a lane of a padded row read row M - 1's activations (the clamp) and holds row M - 1's values, bit for bit --
+            // it stores them to row M - 1 again.  (Under `if (mvalid)` every store sits in its own exec branch, the compiler cannot count
+            // them, and the wait for the next tile's rows behind them becomes a drain of the stores.)
+            *(f32x4*)(slab + (size_t)m * D + (wave * NT + t) * 16 + fq * 4) = o;
         }
+        // xs[(mt + 1) & 1] was last read by the FC1 of tile mt - 1: every wave is past two barriers since
+        if (PREFETCH) lstore_x(mt + 1);
+    };
+    if (mtiles == 1) {
+        do_tile(0, std::false_type{});
+    } else {
+        for (int mt = 0; mt < mtiles; ++mt) do_tile(mt, std::true_type{});
     }
 }
 
