@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
     constexpr int NT = (D / 16) / 4;                        // FC2 output tiles (16 columns) per wave
     static_assert((D / 16) % 4 == 0, "D must be a multiple of 64");
     __shared__ __attribute__((aligned(16))) bf16_t hs[2][16][72];     // h of one m-tile (two buffers), row pitch 144 B
-    // The 16 activation rows of an m-tile, staged by LDS-DMA (two buffers): 16-byte piece c of row m sits in slot 4 K32 m + (c ^ (m & 7)).
+    // The 16 activation rows of an m-tile in LDS (two buffers; global -> registers -> LDS, see gload_x): 16-byte piece c of row m sits in slot 4 K32 m + (c ^ (m & 7)).
     // (The FC1 chain used to fetch its activation fragments from global memory: 8 requested up front, the other 16 one at a time INSIDE
     // the chain -- there are no registers to hold them next to 192 of weight fragments -- i.e. 16 dependent round trips per launch:
     // "L W1 L W1 ..." in tools/isa_waits.py, 6 of the launch's 9 us.  From LDS a fragment is a 64-cycle read that waits for nothing else.)
