@@ -160,10 +160,16 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
         // xs[(mt + 1) & 1] was last read by the FC1 of tile mt - 1: every wave is past two barriers since
         if (PREFETCH) lstore_x(mt + 1);
     };
+    // Pairs: the second tile of a pair is straight-line code behind the first, where the compiler's wait counts are exact.  (Across
+    // a loop's back edge its scoreboard merges "the weights may still be arriving" with "12 slab stores are in flight" and the counted
+    // waits of the FC1 chain come out as vmcnt(1): from the second iteration on that is a drain of the previous tile's stores.)
     if (mtiles == 1) {
         do_tile(0, std::false_type{});
     } else {
-        for (int mt = 0; mt < mtiles; ++mt) do_tile(mt, std::true_type{});
+        for (int mt = 0; mt < mtiles; mt += 2) {
+            do_tile(mt, std::true_type{});
+            if (mt + 1 < mtiles) do_tile(mt + 1, std::true_type{});
+        }
     }
 }
 
