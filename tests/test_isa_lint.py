@@ -1,0 +1,77 @@
+"""Compile-time lint of the product kernels (no GPU: hipcc cross-compiles gfx950 here).  The round-4 gains came from places where the
+hardware was waiting for the compiler -- `vmcnt(0)` where a counted wait was meant, a store drain in front of a load, spills.  These
+checks keep the repaired shapes from coming back unnoticed (tools/isa_waits.py lists a kernel's memory operations and vmcnt waits in
+program order from the compiler's assembly; profiles/r04_*_waits.txt, r04_ffn_txt_counted_staging_ab.txt)."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None, reason="needs hipcc")
+
+# kernels that are allowed a few dwords of scratch (the residual + LayerNorm epilogue of the 256 x 256 tile at 256 VGPRs), in bytes
+SCRATCH_ALLOWED = {"gemm256_kernelILi6E": 68, "gemm256f8_kernelILi6E": 32, "gemm256f8_kernelILi7E": 32}
+FILES = ["attention.hip", "ffn_txt.hip", "gemm.hip", "gemm256.hip", "gemm_f8.hip", "gemm_mt.hip", "preproc.hip", "rowops.hip",
+         "skinny.hip", "student.hip", "txtblock.hip"]
+
+
+@pytest.fixture(scope="module")
+def listings():
+    from isa_waits import kernel_listings
+    out = {}
+    for f in FILES:
+        res, _ = kernel_listings(f, "_Z")
+        assert res, f
+        out[f] = res
+    return out
+
+
+def test_no_product_kernel_spills(listings):
+    seen = 0
+    for f, res in listings.items():
+        for name, vg, scratch, toks in res:
+            seen += 1
+            allowed = max([v for k, v in SCRATCH_ALLOWED.items() if k in name] or [0])
+            assert scratch is not None and scratch <= allowed, f"{f}: {name} uses {scratch} bytes of scratch (allowed {allowed})"
+            assert "xs" not in toks and "xl" not in toks or allowed, f"{f}: {name} has scratch traffic"
+    assert seen >= 150
+
+
+def _one(listings, f, pat):
+    hits = [r for r in listings[f] if pat in r[0]]
+    assert len(hits) == 1, (f, pat, [h[0] for h in hits])
+    return hits[0][3]
+
+
+def test_text_ffn_waits_are_counted(listings):
+    """ffn_txt (GIT-base width, bf16 and e4m3 weights): no LDS-DMA in the kernel (with one the compiler stops counting), and the next
+    m-tile's rows are copied to LDS with the previous tile's 12 slab stores still in flight (vmcnt(17) .. vmcnt(12), not a drain)."""
+    for pat in ("ffn_txt_kernelILi24ELb0", "ffn_txt_kernelILi24ELb1"):
+        toks = _one(listings, "ffn_txt.hip", pat)
+        assert "D" not in toks, pat
+        s = " ".join(toks)
+        assert "S " * 12 + "W17 W16 W15 W14 W13 W12" in s, (pat, s)
+        assert "S " * 12 + "W0" not in s, (pat, s)              # no drain right behind a tile's stores
+
+
+def test_vocabulary_head_requests_rows_ahead_of_weights(listings):
+    """skinny_head: the activation rows are requested first and waited for alone (counted), the weights stay in flight across the
+    first barrier; nothing in front of that barrier waits for everything."""
+    toks = _one(listings, "skinny.hip", "skinny_head_kernelILi24ELb0")
+    first_bar = toks.index("|")
+    head = toks[:first_bar]
+    assert head.count("L") >= 30 and "W0" not in head, head
+    assert any(t.startswith("W") and int(t[1:]) >= 24 for t in head), head
+
+
+def test_row_prologue_three_waves_is_one_round_trip(listings):
+    """skinny_rows3: the row's two slab groups per wave (2 x 8 slabs x 3 vectors) + bias / residual / gamma / beta are all requested
+    before the single wait of the row loop."""
+    toks = _one(listings, "skinny.hip", "skinny_rows3_kernelILi24ELi0")
+    i = toks.index("[")
+    j = toks.index("W0", i)
+    assert toks[i + 1:j].count("L") >= 48 + 12, toks[i:j + 1]

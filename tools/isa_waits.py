@@ -16,10 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "real-time-video-captioning_amd", "csrc")
 
 
-def main():
-    if len(sys.argv) < 3:
-        sys.exit(__doc__)
-    src, pat = sys.argv[1], sys.argv[2]
+def kernel_listings(src, pat):
+    """[(mangled name, NumVgprs, ScratchSize in bytes, tokens)] of every kernel of `src` whose mangled name contains `pat`."""
     src = src if os.path.exists(src) else os.path.join(CSRC, src)
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
@@ -28,16 +26,12 @@ def main():
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         text = open(out).read().splitlines()
     names = [l.split(":")[0] for l in text if re.match(r"^_Z\w+:", l)]
-    hits = [n for n in names if pat in n]
-    if not hits:
-        sys.exit("no kernel matches %r; kernels: %s" % (pat, ", ".join(names)))
-    for name in hits:
+    res = []
+    for name in [n for n in names if pat in n]:
         i = text.index(next(l for l in text if l.startswith(name + ":")))
         toks, vg, sc = [], None, None
         for l in text[i + 1:]:
             t = l.strip()
-            if re.match(r"^_Z\w+:", l) or t.startswith(".section"):
-                pass
             if t.startswith("; NumVgprs:"):
                 vg = t.split(":")[1].strip()
             if t.startswith("; ScratchSize:"):
@@ -74,6 +68,17 @@ def main():
                     toks.append("W" + m.group(1))
             elif op == "s_endpgm":
                 toks.append("END")
+        res.append((name, vg, int(sc) if sc is not None else None, toks))
+    return res, names
+
+
+def main():
+    if len(sys.argv) < 3:
+        sys.exit(__doc__)
+    res, names = kernel_listings(sys.argv[1], sys.argv[2])
+    if not res:
+        sys.exit("no kernel matches %r; kernels: %s" % (sys.argv[2], ", ".join(names)))
+    for name, vg, sc, toks in res:
         print("%s\n  VGPRs %s, scratch %s bytes\n  %s\n" % (name, vg, sc, " ".join(toks)))
 
 
