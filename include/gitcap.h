@@ -90,11 +90,21 @@ int gitcap_set_weight_storage(gitcap_t* h, int storage);
 /* Arithmetic of the image pass (north_star: "MFMA bf16/fp8 GEMMs"; BASELINE configs[4]).  GITCAP_COMPUTE_BF16 (default): every GEMM
  * on bf16 operands.  GITCAP_COMPUTE_FP8_FFN (opt-in; needs e4m3 weight storage and 768- / 1024-wide models): FC1 and FC2 of the
  * image rows run on v_mfma_f32_16x16x128_f8f6f4 with the e4m3 weight codes read as stored and activations quantised to e4m3 with a
- * static scale (codes of value * 16, saturating at +-28) by the producing epilogues; everything else stays bf16.  Results differ from
+ * static scale (default: codes of value * 16, saturating at +-28; gitcap_set_fp8_scale / gitcap_fp8_saturations below) by the
+ * producing epilogues; everything else stays bf16.  Results differ from
  * bf16 compute by the activation rounding (measured |dlogit| <= 0.3 of a spread of 4 on GIT-large: DESIGN.md par. 3 / 6); the oracle's
  * counterpart is GitOracle(emulate_fp8_act="ffn"). */
 enum { GITCAP_COMPUTE_BF16 = 0, GITCAP_COMPUTE_FP8_FFN = 1 };
 int gitcap_set_compute(gitcap_t* h, int compute);
+/* The static scale of the e4m3 activation codes of GITCAP_COMPUTE_FP8_FFN (no reference counterpart: the reference computes in
+ * fp32, src/models/model.py:378, :412-418).  A code holds value / scale; codes reach +-448, so the default 1/16 covers +-28 and
+ * e.g. 1/4 covers +-112 at four times the rounding step.  `scale` must be a power of two in [2^-16, 2^8].  The mode saturates,
+ * but never silently: every code of a valid row that the producing epilogues clamp at +-448 is counted on the device, and
+ * gitcap_fp8_saturations reads (and, with reset != 0, clears) the count since the last reset.  Both calls synchronise the
+ * device.  A caller calibrates by running representative clips and raising the scale until the count stays 0; the oracle's
+ * counterpart is GitOracle(emulate_fp8_act="ffn", fp8_scale=...). */
+int gitcap_set_fp8_scale(gitcap_t* h, float scale);
+int gitcap_fp8_saturations(gitcap_t* h, int64_t* count, int reset);
 int gitcap_weight_bytes(const gitcap_t* h, int64_t* bytes);
 
 /* Replaces: self.image_encoder(torch.stack(batch['image'])) + temporal add + cat(dim=1)

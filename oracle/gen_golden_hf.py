@@ -2,7 +2,7 @@
 (transformers.models.git, HF port of microsoft/GenerativeImage2Text) on OUR seeded synthetic
 weights and inputs.  TEST INFRASTRUCTURE ONLY; run in the build container:
 
-    python oracle/gen_golden_hf.py            # tiny + base fixtures (~5 min of CPU)
+    python oracle/gen_golden_hf.py            # tiny + base + stress fixtures (~8 min of CPU); or: tiny | base | stress
 
 The reference tree has no fixture for this path and its arithmetic package is
 absent, so these vectors pin the oracle (oracle/git_oracle.py) to the one independent
@@ -25,7 +25,7 @@ sys.path.insert(0, os.path.join(ROOT, "real-time-video-captioning_amd"))
 sys.path.insert(0, ROOT)
 
 from gitcap.config import git_base, git_tiny, GitCapConfig          # noqa: E402
-from gitcap.weights import synthetic_weights, to_hf_state_dict      # noqa: E402
+from gitcap.weights import stress_weights, synthetic_weights, to_hf_state_dict      # noqa: E402
 from oracle.git_oracle import make_frames                            # noqa: E402
 
 
@@ -88,10 +88,12 @@ def hf_greedy(model, frames, max_len, cls_id):
     return ids, torch.stack(last, 1), torch.stack(top_i, 1), torch.stack(top_v, 1)
 
 
-def gen_tiny(out_dir):
-    for F in (2, 0):
+def gen_tiny(out_dir, stress=False):
+    """stress=True: the second weight family (gitcap.weights.stress_weights: outlier LayerNorm channels, saturating GELU
+    inputs, large-norm CLS / position rows, a peaked head) -> hf_tiny_stress.npz (F = 2 only)."""
+    for F in ((2,) if stress else (2, 0)):
         cfg = git_tiny(num_frames=F)
-        w = synthetic_weights(cfg, seed=0)
+        w = (stress_weights if stress else synthetic_weights)(cfg, seed=0)
         model = build_hf(cfg, w)
         Fr = max(1, F)
         frames = make_frames(2, Fr, cfg.image_size, seed=1234)
@@ -107,19 +109,20 @@ def gen_tiny(out_dir):
         pv = frames if model.config.num_image_with_embedding is not None else frames[:, 0]
         hs = model(input_ids=ids, pixel_values=pv, use_cache=False, output_hidden_states=True).hidden_states
         hidden = torch.stack([h.float() for h in hs], 0)
-        np.savez_compressed(os.path.join(out_dir, f"hf_tiny_F{F}.npz"), hidden=hidden.detach().numpy(),
+        np.savez_compressed(os.path.join(out_dir, "hf_tiny_stress.npz" if stress else f"hf_tiny_F{F}.npz"), hidden=hidden.detach().numpy(),
                             prefix_ids=ids.numpy(), logits=logits.numpy(), visual=visual.numpy(),
                             projected=proj.detach().numpy(), greedy_ids=gids.numpy(),
                             greedy_top_ids=ti.numpy(), greedy_top_vals=tv.numpy(),
                             weight_seed=0, frame_seed=1234)
-        print(f"tiny F={F}: logits {tuple(logits.shape)} greedy {gids.tolist()}")
+        print(f"tiny F={F}{' stress' if stress else ''}: logits {tuple(logits.shape)} greedy {gids.tolist()}")
 
 
-def gen_base(out_dir):
-    for F, fname in ((0, "hf_base_F1.npz"), (6, "hf_base_F6.npz")):
+def gen_base(out_dir, stress=False):
+    """stress=True: GIT-base, 2 clips x 2 frames on gitcap.weights.stress_weights -> hf_base_F2_stress.npz."""
+    for F, fname in (((2, "hf_base_F2_stress.npz"),) if stress else ((0, "hf_base_F1.npz"), (6, "hf_base_F6.npz"))):
         t0 = time.time()
         cfg = git_base(num_frames=F)
-        w = synthetic_weights(cfg, seed=0)
+        w = (stress_weights if stress else synthetic_weights)(cfg, seed=0)
         model = build_hf(cfg, w)
         del w
         frames = make_frames(2, max(1, F), cfg.image_size, seed=1234)
@@ -142,3 +145,6 @@ if __name__ == "__main__":
         gen_tiny(out)
     if which in ("all", "base"):
         gen_base(out)
+    if which in ("all", "stress"):
+        gen_tiny(out, stress=True)
+        gen_base(out, stress=True)

@@ -59,12 +59,12 @@ def _q8_static(x: torch.Tensor, scale: float) -> torch.Tensor:
     return (x / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32) * scale
 
 
-FP8_FFN_SCALE = 1.0 / 16.0      # static scale of the e4m3 FFN activations (codes cover +-28; gitcap/config.py: the same constant)
+FP8_FFN_SCALE = 1.0 / 16.0      # default static scale of the e4m3 FFN activations (codes cover +-28; csrc/gitcap.hip: f8_scale)
 
 
 class GitOracle:
     def __init__(self, cfg, weights: Dict[str, np.ndarray], emulate_bf16: bool = False,
-                 threads: Optional[int] = None, emulate_fp8_act: bool = False):
+                 threads: Optional[int] = None, emulate_fp8_act: bool = False, fp8_scale: float = FP8_FFN_SCALE):
         self.cfg = cfg
         self.bf = bool(emulate_bf16)
         # True (study, oracle/fp8_act_study.py): the activation operand of every image-row GEMM (not the patch embedding, not
@@ -72,6 +72,8 @@ class GitOracle:
         # "ffn" (the device's opt-in compute="fp8_ffn"): only FC1 and FC2 of the image rows, e4m3 with the static scale
         # FP8_FFN_SCALE, rounded straight from fp32.
         self.f8 = emulate_fp8_act if emulate_fp8_act == "ffn" else bool(emulate_fp8_act)
+        self.f8_scale = float(fp8_scale)   # "ffn" mode: the device's gitcap_set_fp8_scale
+        self.f8_sat = 0                    # "ffn" mode: codes clamped at +-448 so far (the device's gitcap_fp8_saturations)
         if threads:
             torch.set_num_threads(threads)
         self.w: Dict[str, torch.Tensor] = {}
@@ -86,7 +88,11 @@ class GitOracle:
     def _lin(self, x, name, img: bool = False):
         """y = bf16(x) @ bf16(W)^T + b with fp32 accumulation (img: an image-row GEMM, e4m3 activations when emulate_fp8_act)."""
         if img and self.f8 == "ffn":
-            xin = _q8_static(x, FP8_FFN_SCALE) if (name.endswith("fc1") or name.endswith("fc2")) else _r(x, self.bf)
+            if name.endswith("fc1") or name.endswith("fc2"):
+                self.f8_sat += int(((x / self.f8_scale).abs() > 448.0).sum())
+                xin = _q8_static(x, self.f8_scale)
+            else:
+                xin = _r(x, self.bf)
         else:
             xin = _q8(_r(x, self.bf)) if (img and self.f8) else _r(x, self.bf)
         return Fn.linear(xin, self.w[name + ".w"], self.w[name + ".b"])

@@ -48,6 +48,12 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
     return w;
 }
 
+// e4m3 codes that pack_fp8x4 clamps (|value| beyond the largest finite e4m3): the saturation the fp8 activation path must
+// not hide (gitcap_fp8_saturations)
+__device__ __forceinline__ int count_fp8_clamped(f32x4 c) {
+    return (int)(fabsf(c[0]) > 448.f) + (int)(fabsf(c[1]) > 448.f) + (int)(fabsf(c[2]) > 448.f) + (int)(fabsf(c[3]) > 448.f);
+}
+
 // 16-byte-chunk XOR swizzle for [rows][64 bf16] (128-B row) LDS tiles read with ds_read_b128 by
 // MFMA operand lanes (row = lane&15 or lane&31, chunk = k/8).  g(row) = (row>>1)&7 makes every
 // ds_read_b128 lane group hit 16 distinct 16-B slots of the 256-B bank row for both the
@@ -71,6 +77,15 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
+}
+
+// one (non-returning) atomic per wave that clamped at least one e4m3 code: total += the wave's count
+__device__ __forceinline__ void report_fp8_clamped(unsigned long long* total, int nsat, int lane) {
+    if (!total) return;
+    const unsigned long long any = __ballot(nsat != 0);
+    if (any == 0) return;
+    const int n = (int)wave_sum((float)nsat);              // <= 64 lanes x 128 codes: exact in fp32
+    if (lane == 0) (void)__hip_atomic_fetch_add(total, (unsigned long long)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // The library is compiled with -ffp-contract=off: the compiler never fuses a multiply with an add on its own, so the

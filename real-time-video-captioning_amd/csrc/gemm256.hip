@@ -47,7 +47,7 @@ constexpr int LDS_TOTAL = 8 * EPI_REGION;        // 139264 B >= 2 * STAGE
 #define WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-template <int EPI>
+template <int EPI, bool LN8 = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
 
     // ---- epilogue through LDS (gemm_epilogue.h; the operand stages are dead after the last barrier) ----
     if (EPI == EPI_RESID_LN_PRE || EPI == EPI_RESID_LN_POST)
-        gemm_epilogue_tile_ln<EPI == EPI_RESID_LN_POST>(a, acc, smem, m0, n0, tm, tn, wid, wm, wn, lane);
+        gemm_epilogue_tile_ln<EPI == EPI_RESID_LN_POST, false, LN8>(a, acc, smem, m0, n0, tm, tn, wid, wm, wn, lane);
     else
         gemm_epilogue_wave<EPI>(a, acc, smem + wid * EPI_REGION, m0 + wm * 64, n0 + wn * 128, lane);
 #ifdef LN_STAMPS
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
 #endif
 }
 
-template <int EPI>
+template <int EPI, bool LN8 = false>
 hipError_t launch_t(const GemmArgs& a0, hipStream_t s) {
     static bool attr_done[64] = {false};            // per device: the attribute belongs to the device's code object
     int dev_ = 0;
@@ -282,7 +282,7 @@ hipError_t launch_t(const GemmArgs& a0, hipStream_t s) {
     bool& attr_set = attr_done[dev_ & 63];
     constexpr int LDS = (EPI == EPI_RESID_LN_PRE || EPI == EPI_RESID_LN_POST) ? LN_LDS_TOTAL : LDS_TOTAL;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, LN8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -293,7 +293,7 @@ hipError_t launch_t(const GemmArgs& a0, hipStream_t s) {
         a.ln_rowblock_map = ln_use_rowblock_map(a.M >> 8, a.N >> 8, device_cus()) ? 1 : 0;
         if (a.ln_rowblock_map) grid = ln_grid_size(a.M >> 8, a.N >> 8);
     }
-    hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(grid), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, LN8>), dim3(grid), dim3(512), LDS, s, a);
     return hipGetLastError();
 }
 
@@ -310,8 +310,9 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
         case EPI_BIAS_RESID_F32: return launch_t<EPI_BIAS_RESID_F32>(a, s);
         case EPI_BIAS_F32: return launch_t<EPI_BIAS_F32>(a, s);
         case EPI_PATCH_F32: return launch_t<EPI_PATCH_F32>(a, s);
-        case EPI_RESID_LN_PRE: return gemm256_ln_ok(a) && a.resid ? launch_t<EPI_RESID_LN_PRE>(a, s) : hipErrorInvalidValue;
-        case EPI_RESID_LN_POST: return gemm256_ln_ok(a) && a.out ? launch_t<EPI_RESID_LN_POST>(a, s) : hipErrorInvalidValue;
+        // (a.ln_out8: the instantiation that also writes the e4m3 copy of the LayerNorm output, fp8 compute)
+        case EPI_RESID_LN_PRE: return !(gemm256_ln_ok(a) && a.resid) ? hipErrorInvalidValue : a.ln_out8 ? launch_t<EPI_RESID_LN_PRE, true>(a, s) : launch_t<EPI_RESID_LN_PRE>(a, s);
+        case EPI_RESID_LN_POST: return !(gemm256_ln_ok(a) && a.out) ? hipErrorInvalidValue : a.ln_out8 ? launch_t<EPI_RESID_LN_POST, true>(a, s) : launch_t<EPI_RESID_LN_POST>(a, s);
     }
     return hipErrorInvalidValue;
 }

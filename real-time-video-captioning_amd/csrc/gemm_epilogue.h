@@ -38,6 +38,7 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& a, const f32x
     // is waited for with vmcnt(0) (LDS-DMA earlier in the kernel: the compiler counts nothing), and on gfx9 that also waits for
     // every store of the first half to be acknowledged.
     f32x4 bias8[2][4], sc8[2][SCALED ? 4 : 1];
+    int nsat = 0;                                          // OUT_F8: codes of valid rows this lane clamped at +-448 (gitcap_fp8_saturations)
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -70,7 +71,9 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& a, const f32x
                         for (int r = 0; r < 4; ++r) v[r] = erf_gelu(v[r]);
                     }
                     if (OUT_F8) {
-                        *(unsigned*)(ep + ml * RS + nl) = pack_fp8x4(v[0] * a.out8_inv, v[1] * a.out8_inv, v[2] * a.out8_inv, v[3] * a.out8_inv);
+                        const f32x4 c = v * a.out8_inv;
+                        if (mw + ml < a.valid_rows) nsat += count_fp8_clamped(c);
+                        *(unsigned*)(ep + ml * RS + nl) = pack_fp8x4(c[0], c[1], c[2], c[3]);
                     } else if (OUT_BF16) {
                         uint2 o;
                         o.x = pack_bf2(v[0], v[1]);
@@ -123,6 +126,7 @@ __device__ __forceinline__ void gemm_epilogue_wave(const GemmArgs& a, const f32x
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      // reads done before the next half-block overwrites
     }
+    if (OUT_F8) report_fp8_clamped(a.f8_sat, nsat, lane);
 }
 
 // ---- residual + LayerNorm epilogue of a whole 256x256 tile (EPI_RESID_LN_*; gemm256.hip) ------------------------
@@ -147,7 +151,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 // (sc1) statistics stores with s_waitcnt vmcnt(0) before the workgroup barrier that precedes the arrival, the arrival and
 // the poll are agent-scope atomics, and the statistics are fetched with sc1 loads issued after the poll succeeded (the
 // "write-through store; drain; flag" form of MI355X_MICROARCH.md; agent-scope fences measured 5.4 vs 1.9 us per exchange).
-template <bool POST, bool SCALED = false>
+// LN8: the instantiation that also writes the e4m3 copy of the LayerNorm output (a.ln_out8, fp8 compute) and counts the codes it
+// clamps; the default instantiation carries none of that code (registers: the epilogue runs at the 256-VGPR limit).
+template <bool POST, bool SCALED = false, bool LN8 = false>
 __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f32x4 (&acc)[2][4][2][2], char* smem,
                                                       const int m0, const int n0, const int tm, const int tn,
                                                       const int wid, const int wm, const int wn, const int lane) {
@@ -279,6 +285,7 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
     LN_STAMP(6);
     // (the optional per-row addend -- the temporal embedding on the last ViT block -- as a second instantiation: a load inside the
     // loop, even one that is never executed, leaves a vmcnt(0) behind every row's stores)
+    int nsat = 0;                                          // ln_out8: codes of valid rows this lane clamped at +-448
     auto phase2 = [&](auto has_add_c) {
     constexpr bool HAS_ADD = decltype(has_add_c)::value;
 #pragma unroll
@@ -299,11 +306,16 @@ __device__ __forceinline__ void gemm_epilogue_tile_ln(const GemmArgs& a, const f
             o.y = pack_bf2(y[2], y[3]);
             *(uint2*)(a.ln_out + m * a.ld_ln + n) = o;
             // fp8 compute: the e4m3 copy the next (fp8) GEMM reads, straight from the fp32 value
-            if (a.ln_out8) *(unsigned*)(a.ln_out8 + m * a.ld_ln8 + n) = pack_fp8x4(y[0] * a.ln_out8_inv, y[1] * a.ln_out8_inv, y[2] * a.ln_out8_inv, y[3] * a.ln_out8_inv);
+            if (LN8) {
+                const f32x4 c = y * a.ln_out8_inv;
+                if (mw + ml < a.valid_rows) nsat += count_fp8_clamped(c);
+                *(unsigned*)(a.ln_out8 + m * a.ld_ln8 + n) = pack_fp8x4(c[0], c[1], c[2], c[3]);
+            }
         }
     }
     };
     if (!POST && a.ln_add) phase2(std::true_type{}); else phase2(std::false_type{});
+    if (LN8) report_fp8_clamped(a.f8_sat, nsat, lane);
 #ifdef LN_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     LN_STAMP(7);

@@ -104,6 +104,8 @@ struct gitcap {
     int nslab_max = 16;                 // fp32 split-K slabs per text row the workspace holds
     // opt-in fp8 MFMA compute of the image rows' FFN GEMMs (gitcap_set_compute; gemm_f8.hip): e4m3 activation operands
     bool f8ffn = false;
+    float f8_scale = 1.0f / 16.0f;                   // static power-of-two scale of the e4m3 activation codes (gitcap_set_fp8_scale)
+    unsigned long long* f8_sat = nullptr;            // device counter: codes of valid rows the producing epilogues clamped at +-448
     unsigned char *hb8 = nullptr, *ffn8 = nullptr;   // [Mi][Dm] LayerNorm output / [Mi][Fm] GELU output as e4m3 codes of value * 16
     bf16_t *hb = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr, *patches = nullptr, *kv_img = nullptr;
     // workspace (text rows)
@@ -371,23 +373,24 @@ int gemm(gitcap* h, hipStream_t s, int epi, const bf16_t* A, int lda, const WRef
 std::atomic<bool> g_fuse_ln{!env_flag("GITCAP_NO_GEMM_LN")};
 
 // compute = fp8_ffn: FC1 and FC2 of the image rows on v_mfma_f32_16x16x128_f8f6f4 (gemm_f8.hip).  Their activation operands
-// (the LayerNorm output in front of FC1, the GELU output in front of FC2) are written as e4m3 codes of value / kF8Scale by the
-// producing epilogues -- one static power-of-two scale, codes cover +-28, saturating --, the weights are the e4m3 codes of
+// (the LayerNorm output in front of FC1, the GELU output in front of FC2) are written as e4m3 codes of value / f8_scale by the
+// producing epilogues -- one static power-of-two scale per handle (default 1/16: codes cover +-28), saturating, every clamped
+// code of a valid row counted (gitcap_fp8_saturations) --, the weights are the e4m3 codes of
 // e4m3 storage read as they are.  Everything else (q|k|v, attention, output projections, the text rows) stays bf16.  The e4m3
 // copy of a LayerNorm output exists only in the fused GEMM + LayerNorm epilogue, so the mode needs it (a handle whose exchange
 // timed out computes in bf16 from then on).
-constexpr float kF8Scale = 1.0f / 16.0f;
 bool use_f8(const gitcap* h) { return h->f8ffn && g_fuse_ln && !h->xh.degraded; }
 
-// FC1 of the image rows in fp8 compute: A8 = e4m3 codes [M][K] (value / kF8Scale), W = e4m3 storage; out8 = e4m3 codes of
-// GELU(A W^T + bias) / kF8Scale
+// FC1 of the image rows in fp8 compute: A8 = e4m3 codes [M][K] (value / f8_scale), W = e4m3 storage; out8 = e4m3 codes of
+// GELU(A W^T + bias) / f8_scale
 int gemm_f8(gitcap* h, hipStream_t s, int epi, const unsigned char* A8, int lda, const WRef& W, const float* bias, int rows,
             int M, int N, int K, unsigned char* out8, int ldo) {
     if (!W.scale) return fail(h, GITCAP_ERR_STATE, "fp8 compute needs e4m3 weight storage");
     ProfScope ps(h, GITCAP_PROF_GEMM, s, 2.0 * rows * N * K, 1.0 * rows * K + 1.0 * N * K + 1.0 * rows * N);
     GemmArgs a{};
-    a.A = (const bf16_t*)A8; a.lda = lda; a.W = (const bf16_t*)W.p; a.wscale = W.scale; a.ascale = kF8Scale; a.bias = bias;
-    a.M = M; a.N = N; a.K = K; a.out = out8; a.ldo = ldo; a.out8_inv = 1.0f / kF8Scale;
+    a.A = (const bf16_t*)A8; a.lda = lda; a.W = (const bf16_t*)W.p; a.wscale = W.scale; a.ascale = h->f8_scale; a.bias = bias;
+    a.M = M; a.N = N; a.K = K; a.out = out8; a.ldo = ldo; a.out8_inv = 1.0f / h->f8_scale;
+    a.valid_rows = rows; a.f8_sat = h->f8_sat;
     HIP_OK(h, launch_gemm_auto(h, a, epi, s, rows, h->Mi));
     return 0;
 }
@@ -408,8 +411,8 @@ int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const
     // [M][lda bytes] and W the e4m3 storage (FC2 in fp8 compute).  Both exist in the fused epilogue only.
     GemmArgs a{};
     a.A = A; a.lda = lda; a.bias = bias; a.M = M; a.N = N; a.K = K; a.out = xout; a.ldo = N; a.resid = resid; a.ldr = N;
-    a.ln_out8 = ln8; a.ld_ln8 = N; a.ln_out8_inv = 1.0f / kF8Scale;
-    if (f8in) { a.W = (const bf16_t*)W.p; a.wscale = W.scale; a.ascale = kF8Scale; }
+    a.ln_out8 = ln8; a.ld_ln8 = N; a.ln_out8_inv = 1.0f / h->f8_scale; a.f8_sat = h->f8_sat;
+    if (f8in) { a.W = (const bf16_t*)W.p; a.wscale = W.scale; a.ascale = h->f8_scale; }
     const bool force_fused = ln8 != nullptr || f8in;
     a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = eps; a.ln_out = ln_out; a.ld_ln = N; a.ln_stats = h->ln_stats; a.ln_cnt = h->ln_cnt;
     a.ln_stats_rows = h->Mi;
@@ -1440,12 +1443,38 @@ int gitcap_set_compute(gitcap_t* h, int compute) {
             const size_t Dm = std::max(h->Dv, h->D), Fm = std::max(c.enc_ffn, c.dec_ffn);
             int rc = ws_alloc(h, &h->hb8, (size_t)h->Mi * Dm);
             rc = rc ? rc : ws_alloc(h, &h->ffn8, (size_t)h->Mi * Fm);
+            rc = rc ? rc : ws_alloc(h, &h->f8_sat, 1);
             if (rc) return rc;
         }
     }
     HIP_OK(h, hipDeviceSynchronize());          // not between the launches of a submission in flight
     h->f8ffn = compute == GITCAP_COMPUTE_FP8_FFN;
     h->have_image = false;
+    return 0;
+}
+
+int gitcap_set_fp8_scale(gitcap_t* h, float scale) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "set_fp8_scale: null handle");
+    int e = 0;
+    if (!(scale > 0.f) || std::frexp(scale, &e) != 0.5f || e < -15 || e > 9)          // 2^-16 .. 2^8
+        return fail(h, GITCAP_ERR_ARG, "set_fp8_scale: the scale must be a power of two in [2^-16, 2^8]");
+    GUARD(h);
+    HIP_OK(h, hipDeviceSynchronize());          // not between the launches of a submission in flight
+    h->f8_scale = scale;
+    h->have_image = false;
+    return 0;
+}
+
+int gitcap_fp8_saturations(gitcap_t* h, int64_t* count, int reset) {
+    if (!h || !count) return fail(h, GITCAP_ERR_ARG, "fp8_saturations: null argument");
+    GUARD(h);
+    *count = 0;
+    if (!h->f8_sat) return 0;                   // compute = fp8_ffn was never selected: nothing was ever encoded
+    HIP_OK(h, hipDeviceSynchronize());
+    unsigned long long v = 0;
+    HIP_OK(h, hipMemcpy(&v, h->f8_sat, sizeof(v), hipMemcpyDeviceToHost));
+    if (reset) HIP_OK(h, hipMemset(h->f8_sat, 0, sizeof(v)));
+    *count = (int64_t)v;
     return 0;
 }
 

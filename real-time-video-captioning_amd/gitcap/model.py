@@ -77,7 +77,7 @@ class GitCaptioner(nn.Module):
     def __init__(self, cfg: Optional[GitCapConfig] = None, weights: Optional[Mapping[str, np.ndarray]] = None, *,
                  device: str | torch.device = "cuda:0", max_batch: int = 16, max_frames: Optional[int] = None,
                  max_text_len: int = 32, max_beams: int = 1, tokenizer=None, stop: str = "all_sep",
-                 weight_dtype: str = "bf16", compute: str = "bf16",
+                 weight_dtype: str = "bf16", compute: str = "bf16", fp8_scale: Optional[float] = None,
                  # constructor kwargs of the reference student (model.py:55-57); only the ids/vocab matter here
                  vocab_length: Optional[int] = None, cls_token_id: Optional[int] = None,
                  sep_token_id: Optional[int] = None, **_ignored_student_kwargs):
@@ -105,8 +105,11 @@ class GitCaptioner(nn.Module):
         if compute == "fp8_ffn" and weight_dtype != "fp8_e4m3":
             raise ValueError("compute='fp8_ffn' needs weight_dtype='fp8_e4m3' (the fp8 GEMMs read the e4m3 codes as stored)")
         self.compute = compute
+        if fp8_scale is not None and compute != "fp8_ffn":
+            raise ValueError("fp8_scale is the activation scale of compute='fp8_ffn'")
+        self.fp8_scale = None if fp8_scale is None else float(fp8_scale)
         self._kw = dict(max_batch=max_batch, max_frames=max_frames, max_text_len=max_text_len,
-                        max_beams=max_beams, stop=stop, weight_dtype=weight_dtype, compute=compute)
+                        max_beams=max_beams, stop=stop, weight_dtype=weight_dtype, compute=compute, fp8_scale=fp8_scale)
         self._dev = torch.device(device)
         self._handle = None
         self._weights: Optional[Dict[str, np.ndarray]] = None
@@ -140,6 +143,8 @@ class GitCaptioner(nn.Module):
             self._call("gitcap_set_weight_storage", 1)
         if self.compute == "fp8_ffn":           # FC1 / FC2 of the image rows on fp8 MFMA (include/gitcap.h: gitcap_set_compute)
             self._call("gitcap_set_compute", 1)
+            if self.fp8_scale is not None:
+                self._call("gitcap_set_fp8_scale", ctypes.c_float(self.fp8_scale))
 
     def __del__(self):
         try:
@@ -590,6 +595,22 @@ class GitCaptioner(nn.Module):
             self._call("gitcap_profile_read", i, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
             out[name] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
         return out
+
+    def set_fp8_scale(self, scale: float):
+        """Static power-of-two scale of the e4m3 activation codes of compute='fp8_ffn' (gitcap_set_fp8_scale): codes hold
+        value / scale and reach +-448.  Synchronises the device."""
+        self._drain()
+        self._call("gitcap_set_fp8_scale", ctypes.c_float(float(scale)))
+        self.fp8_scale = float(scale)
+        self._kw["fp8_scale"] = self.fp8_scale
+        self._last_memory = None
+
+    def fp8_saturations(self, reset: bool = True) -> int:
+        """Activation codes of valid image rows that compute='fp8_ffn' clamped at +-448 since the last reset
+        (gitcap_fp8_saturations).  0 for any other compute mode.  Synchronises the device."""
+        n = ctypes.c_int64()
+        self._call("gitcap_fp8_saturations", ctypes.byref(n), int(bool(reset)))
+        return n.value
 
     def weight_bytes(self) -> int:
         """Device bytes of the loaded tensors (GEMM weights + scales, tables, biases)."""

@@ -102,6 +102,51 @@ def synthetic_weights(cfg: GitCapConfig, seed: int = 0, head_gain: float = 4.0) 
     return out
 
 
+def stress_weights(cfg: GitCapConfig, seed: int = 0, head_gain: float = 4.0) -> Dict[str, np.ndarray]:
+    """``synthetic_weights`` + the statistics trained CLIP / GIT checkpoints are known for and i.i.d. weights lack
+    (second weight family of the parity tests; fixtures tests/golden/hf_*_stress.npz):
+
+      * outlier channels: LayerNorm gamma x 20 on 4 channels of ``enc.ln_pre`` and of every ``ln2`` (encoder: the FC1
+        operand; decoder: the layer output, i.e. the next q|k|v operand and the head operand);
+      * saturating GELU inputs: the FC1 rows of two hidden units of every layer x 30 (pre-activations of std ~ 24, GELU /
+        QuickGELU outputs far beyond the +-28 the default e4m3 activation scale of compute="fp8_ffn" covers; data
+        dependent, as in trained models -- a constant FC1 bias of + 30 adds the same vector to every row and the captions
+        collapse to one repeated token);
+      * large-norm rows: the CLS embedding, position row 0 and two more position rows of the encoder x 10, text position
+        rows 0 and 1 x 10;
+      * a peaked head: q and k of head 0 x 4 in every attention (scores x 16: near one-hot softmax rows, the online-softmax
+        rescale and the text kernel's partial-state merge on hard cases).
+    """
+    w = synthetic_weights(cfg, seed, head_gain)
+    w = {k: v.copy() for k, v in w.items()}
+    Dv, D = cfg.enc_width, cfg.dec_width
+
+    def chans(name, n, width):
+        return _rng(seed, "stress:" + name).choice(width, size=n, replace=False)
+
+    w["enc.ln_pre.w"][chans("enc.ln_pre", 4, Dv)] *= 20.0
+    for i in range(cfg.enc_layers):
+        p = f"enc.L{i}."
+        w[p + "ln2.w"][chans(p + "ln2", 4, Dv)] *= 20.0
+        w[p + "fc1.w"][chans(p + "fc1", 2, cfg.enc_ffn)] *= 30.0
+        w[p + "qkv.w"][0:64] *= 4.0
+        w[p + "qkv.w"][Dv:Dv + 64] *= 4.0
+    for i in range(cfg.dec_layers):
+        p = f"dec.L{i}."
+        oc = chans(p + "ln2", 4, D)
+        w[p + "ln2.w"][oc] *= 20.0
+        if i + 1 == cfg.dec_layers:      # the head reads these rows: as in trained models, the consumer of an outlier channel
+            w["head.w"][:, oc] /= 20.0   # carries small weights for it (the logits keep their spread; captions stay varied)
+        w[p + "fc1.w"][chans(p + "fc1", 2, cfg.dec_ffn)] *= 30.0
+        w[p + "qkv.w"][0:64] *= 4.0
+        w[p + "qkv.w"][D:D + 64] *= 4.0
+    w["enc.cls"] *= 10.0
+    N = cfg.tokens_per_frame
+    w["enc.pos"][[0, N // 3, N - 1]] *= 10.0
+    w["txt.pos"][[0, 1]] *= 10.0
+    return w
+
+
 # --------------------------------------------------------------------------------------
 # Importers
 # --------------------------------------------------------------------------------------

@@ -815,7 +815,7 @@ def test_config4_fp8_ffn_compute(captioner_cls):
     print(f"configs[4] fp8_ffn: max |dlogit| device vs fp8-emulating oracle {d_own:.3f}, vs bf16-emulating oracle {d_bf16:.3f}, "
           f"fp8 oracle vs bf16 oracle {float((l8 - lb).abs().max()):.3f}")
     assert d_own < 3 * LOGIT_TOL_EMUL, d_own
-    assert d_bf16 < 0.45, d_bf16
+    assert d_bf16 < 0.3, d_bf16                  # the accuracy bar of the mode (DESIGN.md par. 3): measured 0.169
     # the searches run on the same kernels: device-resident == host operator, bitwise
     out = m.infer(fr, beam_size=4, max_steps=15, length_penalty=0.6, on_device=True)
     host = m.infer(fr, beam_size=4, max_steps=15, length_penalty=0.6, on_device=False)
