@@ -214,26 +214,60 @@ def other_configs(dev, note):
                        "cpu_in_cpu_out_25_tokens_ms": round(cpu_io, 3), "device_resident_20_tokens_ms": round(dev20, 3)}
     del m
     note("other_configs: one clip done")
-    # ---- configs[4]: GIT-large, 10-frame clips, beam 4, 15 steps, device-resident search; B = 4 clips ----
+    # ---- configs[4]: GIT-large, 10-frame clips, beam 4, 15 steps, device-resident search; B = 4 / 8 / 16 clips per batch,
+    # one batch at a time (gitcap_beam_search) and three batches in flight (gitcap_beam_search_submit / _wait) ----
     cfg = git_large(10)
-    B, beams, steps = 4, 4, 15
+    beams, steps = 4, 15
     wq = quantize_weights_fp8(synthetic_weights(cfg, seed=0))
-    fr = torch.randn(B, 10, 3, cfg.image_size, cfg.image_size, generator=g).to(dev)
+    fr16 = [torch.randn(16, 10, 3, cfg.image_size, cfg.image_size, generator=g).to(dev) for _ in range(2)]
     D, V, Ld, S = cfg.dec_width, cfg.vocab_size, cfg.dec_layers, 10 * cfg.tokens_per_frame
-    c4 = {"workload": "GIT-large (ViT-L/14), 4 clips x 10 frames, beam 4, 15 steps, e4m3-valued weights, device-resident search",
-          "gflop_per_caption": 1975.0}
+    c4 = {"workload": "GIT-large (ViT-L/14), B clips x 10 frames, beam 4, 15 steps, e4m3-valued weights, device-resident search; "
+                      "top-level fields of a storage mode: B = 4", "gflop_per_caption": 1975.0}
     for storage in ("fp8_e4m3", "bf16", "fp8_e4m3+fp8_ffn"):         # the last: FC1 / FC2 of the image rows on fp8 MFMA (opt-in compute)
-        m = GitCaptioner(cfg, wq, device=dev, max_batch=B, max_frames=10, max_text_len=20, max_beams=beams,
+        m = GitCaptioner(cfg, wq, device=dev, max_batch=16, max_frames=10, max_text_len=20, max_beams=beams,
                          weight_dtype=storage.split("+")[0], compute="fp8_ffn" if storage.endswith("fp8_ffn") else "bf16")
-        dt = med_ms(lambda: m.infer(fr, beam_size=beams, max_steps=steps), n=5)
-        di = med_ms(lambda: m.forward_image_enc(fr), n=5)
         wbytes = (Ld * (4 * D * D + 2 * D * cfg.dec_ffn) + D * V) * (1.0 if storage.startswith("fp8_e4m3") else 2.0)
-        kv = sum(B * beams * Ld * 2 * (S + t + 1) * D * 2.0 for t in range(steps - 1))
-        lp = dt - di
-        c4[storage] = {"ms_per_batch": round(dt, 3), "captions_per_s": round(B * 1e3 / dt, 1),
-                       "mfma_frac": round(B * 1e3 / dt * 1975.0 / 1e3 / MFMA_PEAK_TFLOPS, 4), "image_pass_ms": round(di, 3),
-                       "search_loop_ms": round(lp, 3), "search_loop_hbm_frac": round(((steps - 1) * wbytes + kv) / (lp * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                       "weight_mbytes": round(m.weight_bytes() / 1e6, 1)}
+        rec = {}
+        for B in ((4,) if storage == "bf16" else (4, 8, 16)):
+            ins4 = [x[:B] for x in fr16]
+            want = m.infer(ins4[0], beam_size=beams, max_steps=steps)["predictions"].clone()
+            dt = med_ms(lambda: m.infer(ins4[0], beam_size=beams, max_steps=steps), n=5)
+            di = med_ms(lambda: m.forward_image_enc(ins4[0]), n=5)
+            kv = sum(B * beams * Ld * 2 * (S + t + 1) * D * 2.0 for t in range(steps - 1))
+            lp = dt - di
+
+            def pipe4(n, check=False):
+                pend, ok = [], True
+                for i in range(n):
+                    pend.append((i % 2, m.infer_async(ins4[i % 2], beam_size=beams, max_steps=steps)))
+                    if len(pend) == 3:
+                        k, f = pend.pop(0)
+                        r = f.result()
+                        ok = ok and (k != 0 or not check or bool(torch.equal(r["predictions"], want)))
+                while pend:
+                    k, f = pend.pop(0)
+                    r = f.result()
+                    ok = ok and (k != 0 or not check or bool(torch.equal(r["predictions"], want)))
+                return ok
+            same = pipe4(4, check=True)
+            torch.cuda.synchronize(dev)
+            nb = 12 if B <= 8 else 8
+            t0 = time.perf_counter()
+            pipe4(nb)
+            torch.cuda.synchronize(dev)
+            pp = (time.perf_counter() - t0) / nb * 1e3
+            r = {"ms_per_batch": round(dt, 3), "captions_per_s": round(B * 1e3 / dt, 1),
+                 "mfma_frac": round(B * 1e3 / dt * 1975.0 / 1e3 / MFMA_PEAK_TFLOPS, 4), "image_pass_ms": round(di, 3),
+                 "search_loop_ms": round(lp, 3), "search_loop_hbm_frac": round(((steps - 1) * wbytes + kv) / (lp * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "pipelined_ms_per_batch": round(pp, 3), "pipelined_captions_per_s": round(B * 1e3 / pp, 1),
+                 "pipelined_mfma_frac": round(B * 1e3 / pp * 1975.0 / 1e3 / MFMA_PEAK_TFLOPS, 4),
+                 "pipelined_equals_synchronous": same}
+            if B == 4:
+                rec.update(r)
+                rec["weight_mbytes"] = round(m.weight_bytes() / 1e6, 1)
+            else:
+                rec[f"B={B}"] = r
+        c4[storage] = rec
         del m
         note(f"other_configs: configs[4] {storage} done")
     out["configs[4]"] = c4
@@ -336,13 +370,15 @@ def main():
     # the batches before it, on the library's streams); every batch is submitted AND completed (ids gathered)
     # inside the timed region.  --serial runs one batch at a time.  The region (barrier + synchronize on both sides,
     # max over ranks) is repeated --repeats times and the median repeat is reported.
-    def timed_region():
+    def timed_region(inflight=None, serial_mode=None):
+        inflight = args.inflight if inflight is None else inflight
+        serial_mode = args.serial if serial_mode is None else serial_mode
         ev_sub = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
         ev_done = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
         out = None
         fence()
         t0 = time.perf_counter()
-        if args.serial:
+        if serial_mode:
             for i in range(args.steps):
                 ev_sub[i].record()
                 out = step(i)
@@ -352,7 +388,7 @@ def main():
             for i in range(args.steps):
                 ev_sub[i].record()
                 pending.append((i, model.greedy_decode_async(inputs[i % NIN], max_len=TOKENS, stop="never", coalesce=args.coalesce)))
-                if len(pending) == args.inflight * args.coalesce:
+                if len(pending) == inflight * args.coalesce:
                     j, fut = pending.pop(0)
                     out = finish(fut.result())
                     ev_done[j].record()
@@ -396,6 +432,20 @@ def main():
         pipelined_equals_serial = ok
 
     note(f"pipelined == serial screen: {pipelined_equals_serial}")
+    # ---- the latency / throughput frontier (BASELINE.json metric: "captions/sec + p50 latency"): the same K-step region with
+    # one batch at a time, two and three (four) batches in flight; the headline is one of these points ----
+    frontier = None
+    if not args.plain and not args.serial:
+        frontier = []
+        for nf in (1, 2, 3, 4):
+            if nf == args.inflight:
+                el_f, p_f = elapsed, p50
+            else:
+                rs = sorted(timed_region(inflight=max(nf, 2), serial_mode=(nf == 1)) for _ in range(3))
+                el_f, p_f = rs[1]
+            frontier.append({"batches_in_flight": nf * args.coalesce, "captions_per_s": round(world * CLIPS_PER_GPU * args.steps / el_f, 1),
+                             "p50_latency_ms": round(p_f, 3), "headline": nf == args.inflight})
+        note("latency frontier done")
     # ---- unpipelined reference point: one batch at a time (what a single real-time caller sees) ----
     serial = None
     if not args.serial and not args.plain:
@@ -538,7 +588,7 @@ def main():
                        "clips_per_gpu": CLIPS_PER_GPU, "frames": FRAMES, "tokens": TOKENS, "global_batch": world * CLIPS_PER_GPU,
                        "parallelism": f"dp{world}", "batches_in_flight": 1 if args.serial else args.inflight * args.coalesce, "coalesce": args.coalesce, "collective": "all_gather(int64[16,21]) per step" if use_dist else "none", "distinct_input_batches": NIN},
             "caption_mfma_frac": round(value / world * GFLOP_PER_CAPTION / 1e3 / MFMA_PEAK_TFLOPS, 4),
-            "pipelined_equals_serial": pipelined_equals_serial,
+            "pipelined_equals_serial": pipelined_equals_serial, "latency_frontier": frontier,
             "serial": serial, "roofline": roofline, "cpu_baseline": cpu, "other_configs": others, "breakdown": breakdown,
         }
         if pipelined_equals_serial is False:

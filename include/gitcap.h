@@ -204,6 +204,18 @@ int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max
                          int64_t* ids_out, int32_t* steps_out, void* stream, int* ticket);
 int gitcap_greedy_wait(gitcap_t* h, int ticket, void* stream);
 
+/* The same pipelined form for gitcap_beam_search (BASELINE configs[4]; the reference's teacher runs this search one clip at a time,
+ * src/models/model.py:762-768 with the defaults of :702-708): the image pass of one batch overlaps the search loops of the batches
+ * before it.  Tickets of both submit forms share one sequence (at most FOUR submissions of either kind in flight);
+ * gitcap_beam_search_wait is gitcap_greedy_wait under the name that pairs with this call.  visual_out (nullable): as in gitcap_encode
+ * (the `visual_features` of the reference's output dict, model.py:460).  step_logits_out (nullable): device fp32
+ * [max_steps - 1][B * beams][vocab], the raw logits of every search step (what model.py:521 appends to saved_logits).
+ * Results are bitwise those of gitcap_beam_search. */
+int gitcap_beam_search_submit(gitcap_t* h, const float* frames, int B, int F, float* visual_out, int beams, int max_steps,
+                              float length_penalty, int per_node_beam_size,
+                              int64_t* decoded_out, float* logprobs_out, float* step_logits_out, void* stream, int* ticket);
+int gitcap_beam_search_wait(gitcap_t* h, int ticket, void* stream);
+
 /* Health of the in-kernel statistics exchange (no reference counterpart).  The residual GEMMs that normalise their own output
  * rows exchange LayerNorm statistics between the workgroups of a row block (co-residency).  If a workgroup ever
  * gives up waiting (about 30 s: its siblings cannot become resident because another process or a CU-masked stream holds the
@@ -211,7 +223,9 @@ int gitcap_greedy_wait(gitcap_t* h, int ticket, void* stream);
  * checks the flag first and gitcap_poll_errors checks it on demand (call it after synchronising the stream to vouch for the
  * results just produced).  Once raised: the device is drained, the flag is cleared, the handle switches for good to the
  * unfused GEMM + LayerNorm launches (bitwise the same results) and GITCAP_ERR_EXCHANGE is returned ONCE -- the caller
- * re-runs the calls whose results it had not yet vouched for.  Returns 0 when healthy. */
+ * re-runs the calls whose results it had not yet vouched for.  Submissions (gitcap_greedy_submit / gitcap_beam_search_submit)
+ * that were in flight at that moment are marked: their gitcap_*_wait returns GITCAP_ERR_EXCHANGE every time it is called, so a
+ * retry cannot hand out their undefined ids; they must be submitted again.  Returns 0 when healthy. */
 int gitcap_poll_errors(gitcap_t* h);
 
 /* Beam reorder of the text part of the KV cache (what src/models/model.py:623-634 sketches):

@@ -114,7 +114,7 @@ struct gitcap {
     unsigned* row_cnt = nullptr;
     bf16_t *xsb = nullptr, *fs = nullptr, *kv_txt = nullptr, *kv_txt2 = nullptr;
     int32_t* sep_cnt = nullptr;
-    BeamBuffers beam{};                 // device-resident beam-search state (gitcap_beam_search)
+    BeamBuffers beam{};                 // device-resident beam-search state (views into the selected slot)
     float* beam_logits = nullptr;       // [R][V]
     float* cand_scores = nullptr;       // [B][16]
     int* cand_idx = nullptr;
@@ -144,6 +144,8 @@ struct gitcap {
         float *xs = nullptr, *xs2 = nullptr, *slabs = nullptr, *part = nullptr, *amax_val = nullptr; int* amax_idx = nullptr;
         unsigned* row_cnt = nullptr;
         bf16_t *xsb = nullptr, *fs = nullptr, *kv_txt = nullptr, *kv_txt2 = nullptr;
+        // device-resident beam-search state of the slot (gitcap_beam_search / _submit)
+        BeamBuffers beam{}; float* beam_logits = nullptr; float* cand_scores = nullptr; int* cand_idx = nullptr; char* topk_scratch = nullptr;
         int B = 0, S = 0; bool have = false, used = false;
         hipEvent_t ev_in = nullptr, ev_enc = nullptr, ev_dec = nullptr;
         hipStream_t s_txt = nullptr;
@@ -151,6 +153,7 @@ struct gitcap {
     static constexpr int NSLOT = 4;
     Slot slots[NSLOT];
     int cur_slot = 0, next_ticket = 0;
+    int poison_upto = 0;    // tickets below this were in flight when the statistics exchange failed: their results are undefined
     hipStream_t s_enc = nullptr;
     hipStream_t txt_streams[NSLOT] = {nullptr, nullptr, nullptr, nullptr};   // owned; slot i decodes on txt_streams[i % n_txt]
     int n_txt = NSLOT;
@@ -203,6 +206,7 @@ void select_slot(gitcap* h, int i) {
     h->kv_img = n.kv_img; h->sep_cnt = n.sep_cnt; h->cur_B = n.B; h->cur_S = n.S; h->have_image = n.have;
     h->xs = n.xs; h->xs2 = n.xs2; h->slabs = n.slabs; h->part = n.part; h->row_cnt = n.row_cnt; h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
     h->xsb = n.xsb; h->fs = n.fs; h->kv_txt = n.kv_txt; h->kv_txt2 = n.kv_txt2;
+    h->beam = n.beam; h->beam_logits = n.beam_logits; h->cand_scores = n.cand_scores; h->cand_idx = n.cand_idx; h->topk_scratch = n.topk_scratch;
     h->cur_slot = i;
 }
 
@@ -227,6 +231,7 @@ hipError_t join_async(gitcap* h, hipStream_t stream) {
 int poll_exchange(gitcap* h) {
     if (!h->ln_fail || !exchange_poll(h->xh, *(volatile unsigned*)h->ln_fail)) return 0;
     (void)hipDeviceSynchronize();
+    h->poison_upto = h->next_ticket;            // every submission made so far may hold undefined rows: its wait says so, every time
     *(volatile unsigned*)h->ln_fail = 0;
     if (h->ln_cnt) (void)hipMemset(h->ln_cnt, 0, h->ln_cnt_words * sizeof(unsigned));
     return fail(h, GITCAP_ERR_EXCHANGE, "a GEMM + LayerNorm launch timed out waiting for its sibling tiles (CUs held by another "
@@ -652,6 +657,32 @@ int check_frames(gitcap* h, const void* frames, int B, int F, bool raw = false) 
 struct FrameSrc { const float* f32; const uint8_t* u8; int H, W; };     // fp32 NCHW (CLIP-normalised) or raw uint8 HWC BGR
 static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out, hipStream_t stream);
 
+// Pipelined submission: the image pass on the encoder stream, `text_loop` on the slot's decode stream (see gitcap_greedy_submit)
+template <typename TextLoop>
+static int submit_common(gitcap* h, const float* frames, int B, int F, float* visual_out, hipStream_t stream, int* ticket, TextLoop text_loop) {
+    const int slot = ticket_slot(h->next_ticket, gitcap::NSLOT);
+    gitcap::Slot& sl = h->slots[slot];
+    select_slot(h, slot);
+    // the image pass may start once the caller's stream has produced `frames` ...
+    HIP_OK(h, hipEventRecord(sl.ev_in, stream));
+    HIP_OK(h, hipStreamWaitEvent(h->s_enc, sl.ev_in, 0));
+    // ... and once the previous user of this slot's image K/V (four submissions ago) has finished decoding
+    if (sl.used) HIP_OK(h, hipStreamWaitEvent(h->s_enc, sl.ev_dec, 0));
+    h->pipelined = true;
+    int rc = encode_impl(h, FrameSrc{frames, nullptr, 0, 0}, B, F, visual_out, h->s_enc);
+    h->pipelined = false;
+    if (rc) { select_slot(h, 0); return rc; }
+    HIP_OK(h, hipEventRecord(sl.ev_enc, h->s_enc));
+    HIP_OK(h, hipStreamWaitEvent(sl.s_txt, sl.ev_enc, 0));
+    if ((rc = text_loop(sl.s_txt))) { select_slot(h, 0); return rc; }
+    HIP_OK(h, hipEventRecord(sl.ev_dec, sl.s_txt));
+    sl.used = true;
+    *ticket = h->next_ticket++;
+    select_slot(h, 0);
+    return 0;
+}
+
+
 extern "C" {
 
 int gitcap_abi_version(void) { return GITCAP_ABI_VERSION; }
@@ -727,28 +758,29 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
         rc = rc ? rc : ws_alloc(h, &sl.amax_idx, Mt * (size_t)((h->V + 15) / 16));
         rc = rc ? rc : ws_alloc(h, &sl.kv_txt, (size_t)c.dec_layers * h->R * h->Tmax * 3 * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.kv_txt2, (size_t)c.dec_layers * h->R * h->Tmax * 3 * h->D);
-    }
-    {   // beam-search state (slot-independent: the synchronous beam path uses slot 0)
-        const size_t R = h->R, T = (size_t)h->Tmax + 1, Bm = c.max_batch;
-        rc = rc ? rc : ws_alloc(h, &h->beam.ids0, R * T);
-        rc = rc ? rc : ws_alloc(h, &h->beam.ids1, R * T);
-        rc = rc ? rc : ws_alloc(h, &h->beam.words, R);
-        rc = rc ? rc : ws_alloc(h, &h->beam.hyp_ids, Bm * T);
-        rc = rc ? rc : ws_alloc(h, &h->beam.beam_scores, R);
-        rc = rc ? rc : ws_alloc(h, &h->beam.hyp_score, Bm);
-        rc = rc ? rc : ws_alloc(h, &h->beam.src_rows, R);
-        rc = rc ? rc : ws_alloc(h, &h->beam.done, Bm);
-        rc = rc ? rc : ws_alloc(h, &h->beam.hyp_len, Bm);
-        rc = rc ? rc : ws_alloc(h, &h->beam_logits, R * (size_t)h->V);
-        rc = rc ? rc : ws_alloc(h, &h->cand_scores, Bm * 16);
-        rc = rc ? rc : ws_alloc(h, &h->cand_idx, Bm * 16);
-        rc = rc ? rc : ws_alloc(h, &h->topk_scratch, beam_topk_scratch_bytes(c.max_batch, std::max(1, c.max_beams), h->V, 16));
+        {   // beam-search state: per slot, so that searches of different submissions may be in flight together
+            const size_t R = h->R, T = (size_t)h->Tmax + 1, Bm = c.max_batch;
+            rc = rc ? rc : ws_alloc(h, &sl.beam.ids0, R * T);
+            rc = rc ? rc : ws_alloc(h, &sl.beam.ids1, R * T);
+            rc = rc ? rc : ws_alloc(h, &sl.beam.words, R);
+            rc = rc ? rc : ws_alloc(h, &sl.beam.hyp_ids, Bm * T);
+            rc = rc ? rc : ws_alloc(h, &sl.beam.beam_scores, R);
+            rc = rc ? rc : ws_alloc(h, &sl.beam.hyp_score, Bm);
+            rc = rc ? rc : ws_alloc(h, &sl.beam.src_rows, R);
+            rc = rc ? rc : ws_alloc(h, &sl.beam.done, Bm);
+            rc = rc ? rc : ws_alloc(h, &sl.beam.hyp_len, Bm);
+            rc = rc ? rc : ws_alloc(h, &sl.beam_logits, R * (size_t)h->V);
+            rc = rc ? rc : ws_alloc(h, &sl.cand_scores, Bm * 16);
+            rc = rc ? rc : ws_alloc(h, &sl.cand_idx, Bm * 16);
+            rc = rc ? rc : ws_alloc(h, &sl.topk_scratch, beam_topk_scratch_bytes(c.max_batch, std::max(1, c.max_beams), h->V, 16));
+        }
     }
     if (!rc) {   // select slot 0
         gitcap::Slot& n = h->slots[0];
         h->sep_cnt = n.sep_cnt; h->xs = n.xs; h->xs2 = n.xs2; h->slabs = n.slabs; h->part = n.part; h->row_cnt = n.row_cnt;
             h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
         h->xsb = n.xsb; h->fs = n.fs; h->kv_txt = n.kv_txt; h->kv_txt2 = n.kv_txt2;
+        h->beam = n.beam; h->beam_logits = n.beam_logits; h->cand_scores = n.cand_scores; h->cand_idx = n.cand_idx; h->topk_scratch = n.topk_scratch;
     }
     if (!rc) {
         // plain non-blocking streams for the pipeline (stream priorities measured neutral and
@@ -1153,26 +1185,9 @@ int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max
     POLL(h);
     int rc = greedy_check(h, max_len, stop, ids_out);
     if (rc) return rc;
-    const int slot = ticket_slot(h->next_ticket, gitcap::NSLOT);
-    gitcap::Slot& sl = h->slots[slot];
-    select_slot(h, slot);
-    // the image pass may start once the caller's stream has produced `frames` ...
-    HIP_OK(h, hipEventRecord(sl.ev_in, (hipStream_t)stream));
-    HIP_OK(h, hipStreamWaitEvent(h->s_enc, sl.ev_in, 0));
-    // ... and once the previous user of this slot's image K/V (two submissions ago) has finished decoding
-    if (sl.used) HIP_OK(h, hipStreamWaitEvent(h->s_enc, sl.ev_dec, 0));
-    h->pipelined = true;
-    rc = encode_impl(h, FrameSrc{frames, nullptr, 0, 0}, B, F, nullptr, h->s_enc);
-    h->pipelined = false;
-    if (rc) return rc;
-    HIP_OK(h, hipEventRecord(sl.ev_enc, h->s_enc));
-    HIP_OK(h, hipStreamWaitEvent(sl.s_txt, sl.ev_enc, 0));
-    if ((rc = greedy_text_loop(h, B, max_len, stop, ids_out, steps_out, sl.s_txt))) return rc;
-    HIP_OK(h, hipEventRecord(sl.ev_dec, sl.s_txt));
-    sl.used = true;
-    *ticket = h->next_ticket++;
-    select_slot(h, 0);
-    return 0;
+    return submit_common(h, frames, B, F, nullptr, (hipStream_t)stream, ticket, [&](hipStream_t s) {
+        return greedy_text_loop(h, B, max_len, stop, ids_out, steps_out, s);
+    });
 }
 
 int gitcap_greedy_wait(gitcap_t* h, int ticket, void* stream) {
@@ -1181,15 +1196,14 @@ int gitcap_greedy_wait(gitcap_t* h, int ticket, void* stream) {
     POLL(h);
     if (!ticket_waitable(ticket, h->next_ticket, gitcap::NSLOT))
         return fail(h, GITCAP_ERR_ARG, "greedy_wait: ticket is not one of the submissions in flight");
+    if (ticket < h->poison_upto)
+        return fail(h, GITCAP_ERR_EXCHANGE, "this submission was in flight when a GEMM + LayerNorm launch timed out waiting for its sibling "
+                    "tiles: its results are undefined -- submit it again (the handle now uses separate LayerNorm launches)");
     HIP_OK(h, hipStreamWaitEvent((hipStream_t)stream, h->slots[ticket_slot(ticket, gitcap::NSLOT)].ev_dec, 0));
     return 0;
 }
 
-int gitcap_beam_search(gitcap_t* h, const float* frames, int B, int F, int beams, int max_steps, float length_penalty,
-                       int per_node_beam_size, int64_t* decoded_out, float* logprobs_out, void* stream) {
-    if (!h) return fail(h, GITCAP_ERR_ARG, "beam_search: null handle");
-    GUARD(h);
-    POLL(h);
+static int beam_check(gitcap* h, int beams, int max_steps, int per_node_beam_size, const int64_t* decoded_out, const float* logprobs_out) {
     if (!decoded_out || !logprobs_out || beams < 1 || per_node_beam_size < 1) return fail(h, GITCAP_ERR_ARG, "beam_search: bad arguments");
     if (beams > h->c.max_beams || beams > 16 || beams * per_node_beam_size > 16)
         return fail(h, GITCAP_ERR_ARG, "beam_search: beams exceed max_beams / 16 candidates");
@@ -1197,12 +1211,15 @@ int gitcap_beam_search(gitcap_t* h, const float* frames, int B, int F, int beams
     // with fewer than 2 candidates per beam one EOS candidate leaves a sentence short of `beams` live beams, which the
     // reference asserts against (model.py:606); the device bookkeeping has no way to report it, so refuse up front
     if (per_node_beam_size < 2) return fail(h, GITCAP_ERR_ARG, "beam_search: per_node_beam_size must be >= 2 (model.py:606)");
-    hipStream_t s = (hipStream_t)stream;
-    select_slot(h, 0);
-    HIP_OK(h, join_async(h, s));
-    int rc = encode_impl(h, FrameSrc{frames, nullptr, 0, 0}, B, F, nullptr, s);
-    if (rc) return rc;
+    return 0;
+}
+
+// The search loop over the image K/V of the selected slot (its beam state, text K/V and row workspace), on stream s.
+// step_logits_out (nullable): [max_steps - 1][B * beams][V], the raw logits of every step (what model.py:521 saves).
+static int beam_loop(gitcap* h, int B, int beams, int max_steps, float length_penalty, int per_node_beam_size,
+                     int64_t* decoded_out, float* logprobs_out, float* step_logits_out, hipStream_t s) {
     const int rows = B * beams, K = beams * per_node_beam_size, V = h->c.vocab_size, L = max_steps;
+    int rc;
     HIP_OK(h, launch_beam_init(h->beam, B, beams, L, h->c.cls_token_id, s));
     // while cur_len < max_length (model.py:518): the token at position cur_len-1 is decoded, candidates for
     // position cur_len are ranked, bookkept and the text K/V rows follow their beams -- no host round trip
@@ -1213,14 +1230,44 @@ int gitcap_beam_search(gitcap_t* h, const float* frames, int B, int F, int beams
                                              (size_t)h->R * h->Tmax * 3 * h->D, s));
             std::swap(h->kv_txt, h->kv_txt2);
         }
-        rc = text_forward(h, h->beam.words, 1, rows, beams, t, 1, h->beam_logits, 0, nullptr, 0, nullptr, 0, s);
+        float* lg = step_logits_out ? step_logits_out + (size_t)t * rows * V : h->beam_logits;
+        rc = text_forward(h, h->beam.words, 1, rows, beams, t, 1, lg, 0, nullptr, 0, nullptr, 0, s);
         if (rc) return rc;
-        HIP_OK(h, launch_beam_topk(h->beam_logits, V, h->beam.beam_scores, B, beams, V, K, h->cand_scores, h->cand_idx, h->topk_scratch, s));
+        HIP_OK(h, launch_beam_topk(lg, V, h->beam.beam_scores, B, beams, V, K, h->cand_scores, h->cand_idx, h->topk_scratch, s));
         HIP_OK(h, launch_beam_step(h->beam, h->cand_scores, h->cand_idx, B, beams, K, V, cur_len, L, h->c.sep_token_id,
                                    length_penalty, cur, s));
     }
     HIP_OK(h, launch_beam_finish(h->beam, B, L, h->c.sep_token_id, decoded_out, logprobs_out, s));
     return 0;
+}
+
+int gitcap_beam_search_wait(gitcap_t* h, int ticket, void* stream) { return gitcap_greedy_wait(h, ticket, stream); }
+
+int gitcap_beam_search(gitcap_t* h, const float* frames, int B, int F, int beams, int max_steps, float length_penalty,
+                       int per_node_beam_size, int64_t* decoded_out, float* logprobs_out, void* stream) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "beam_search: null handle");
+    GUARD(h);
+    POLL(h);
+    int rc = beam_check(h, beams, max_steps, per_node_beam_size, decoded_out, logprobs_out);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    select_slot(h, 0);
+    HIP_OK(h, join_async(h, s));
+    if ((rc = encode_impl(h, FrameSrc{frames, nullptr, 0, 0}, B, F, nullptr, s))) return rc;
+    return beam_loop(h, B, beams, max_steps, length_penalty, per_node_beam_size, decoded_out, logprobs_out, nullptr, s);
+}
+
+int gitcap_beam_search_submit(gitcap_t* h, const float* frames, int B, int F, float* visual_out, int beams, int max_steps,
+                              float length_penalty, int per_node_beam_size, int64_t* decoded_out, float* logprobs_out,
+                              float* step_logits_out, void* stream, int* ticket) {
+    if (!h || !ticket) return fail(h, GITCAP_ERR_ARG, "beam_search_submit: null argument");
+    GUARD(h);
+    POLL(h);
+    int rc = beam_check(h, beams, max_steps, per_node_beam_size, decoded_out, logprobs_out);
+    if (rc) return rc;
+    return submit_common(h, frames, B, F, visual_out, (hipStream_t)stream, ticket, [&](hipStream_t s) {
+        return beam_loop(h, B, beams, max_steps, length_penalty, per_node_beam_size, decoded_out, logprobs_out, step_logits_out, s);
+    });
 }
 
 int gitcap_reorder_rows(gitcap_t* h, const int32_t* src_rows, int rows, int t_len, void* stream) {

@@ -40,6 +40,9 @@ SYMBOLS = {
     "gitcap_preprocess": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gitcap_beam_topk": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gitcap_beam_search": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "gitcap_beam_search_submit": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, POINTER(c_int)]),
+    "gitcap_beam_search_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "gitcap_reorder_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gitcap_profile_enable": (c_int, [c_void_p, c_int]),
     "gitcap_profile_read": (c_int, [c_void_p, c_int, POINTER(ctypes.c_double), POINTER(c_int64),

@@ -33,40 +33,109 @@ STOP_NEVER, STOP_ALL_SEP = 0, 1
 
 
 class _Submission:
-    """One gitcap_greedy_submit (possibly several coalesced caller batches); keeps its buffers alive."""
+    """One gitcap_greedy_submit / gitcap_beam_search_submit (possibly several coalesced caller batches); keeps its buffers
+    alive until every future attached to it has delivered its result (the frames are what a poisoned submission is re-run from)."""
 
-    def __init__(self, ticket, ids, steps, frames, coalesced):
-        self.ticket, self.ids, self.steps, self.frames, self.coalesced = ticket, ids, steps, frames, coalesced
+    def __init__(self, ticket, frames, outs, coalesced, users=1):
+        self.ticket, self.frames, self.outs, self.coalesced, self.users = ticket, frames, outs, coalesced, users
         self.waited = False
+        self.poisoned = False        # in flight when the LayerNorm statistics exchange failed: results undefined, re-run
+
+    def release(self):
+        self.users -= 1
+        if self.users <= 0:
+            self.frames = None
 
 
-class CaptionFuture:
+class _Future:
+    """Common part of the result handles: wait, vouch for the result where a host synchronisation makes that possible, and
+    re-run the batch on the (by then degraded) handle if the submission was poisoned by a failed statistics exchange."""
+
+    def _deliver(self, extract, synced, rerun):
+        m, sub = self._m, self._sub
+        m._wait_submission(sub)
+        out = None
+        if not sub.poisoned:
+            out = extract()
+            if synced:                         # the data is on the host (or a .item() went through): the flag is meaningful now
+                try:
+                    m.poll_errors()
+                except _lib.GitcapExchangeTimeout:
+                    m._poison_inflight()
+                    sub.poisoned = True
+        if sub.poisoned:
+            out = rerun()
+        sub.release()
+        return out
+
+
+class CaptionFuture(_Future):
     """Result handle of greedy_decode_async."""
 
     def __init__(self, model, frames, mode, max_len, out_device):
         self._m, self._frames, self._mode, self._max_len, self._out_device = model, frames, mode, max_len, out_device
         self._sub, self._r0, self._r1 = None, 0, 0
+        self._done = None
 
     def _attach(self, sub, r0, r1):
         self._sub, self._r0, self._r1 = sub, r0, r1
         self._frames = None                      # the submission holds the (concatenated) frames now
 
     def result(self) -> torch.Tensor:
+        if self._done is not None:
+            return self._done
         m = self._m
         if self._sub is None:                    # still waiting for partners to coalesce with: run now
             m._flush_pending()
         sub = self._sub
-        m._wait_submission(sub)
-        ids = sub.ids[self._r0:self._r1]
-        if self._mode == STOP_ALL_SEP:
-            if sub.coalesced:                    # reference rule over THIS caller batch (model.py:184)
-                all_sep = (ids[:, 1:] == m.sep_token_id).all(dim=0)
-                nz = torch.nonzero(all_sep)
-                n = int(nz[0].item()) + 1 if nz.numel() else self._max_len
-            else:
-                n = int(sub.steps.item())
-            ids = ids[:, :1 + n]
-        return ids.to(self._out_device) if self._out_device != ids.device else ids
+
+        def extract():
+            ids = sub.outs[0][self._r0:self._r1]
+            if self._mode == STOP_ALL_SEP:
+                if sub.coalesced:                    # reference rule over THIS caller batch (model.py:184)
+                    all_sep = (ids[:, 1:] == m.sep_token_id).all(dim=0)
+                    nz = torch.nonzero(all_sep)
+                    n = int(nz[0].item()) + 1 if nz.numel() else self._max_len
+                else:
+                    n = int(sub.outs[1].item())
+                ids = ids[:, :1 + n]
+            return ids.to(self._out_device) if self._out_device != ids.device else ids
+
+        def rerun():
+            ids = m._greedy_decode(sub.frames[self._r0:self._r1], self._max_len, self._mode)
+            return ids.to(self._out_device) if self._out_device != ids.device else ids
+
+        synced = self._mode == STOP_ALL_SEP or self._out_device.type == "cpu"
+        self._done = self._deliver(extract, synced, rerun)
+        return self._done
+
+
+class InferFuture(_Future):
+    """Result handle of infer_async: ``result()`` returns the dict of ``GitCaptioner.infer``."""
+
+    def __init__(self, model, sub, kw, out_device, save_logits):
+        self._m, self._sub, self._kw, self._out_device, self._save = model, sub, kw, out_device, save_logits
+        self._done = None
+
+    def result(self) -> dict:
+        if self._done is not None:
+            return self._done
+        m, sub = self._m, self._sub
+
+        def extract():
+            decoded, logprobs, steps, vis = sub.outs
+            dev = self._out_device
+            mv = lambda t: t if t is None or t.device == dev else t.to(dev)
+            return {"predictions": mv(decoded), "logprobs": mv(logprobs[:, None]),
+                    "logits_dict": [] if steps is None else steps, "visual_features": mv(vis)}
+
+        def rerun():
+            r = m._infer_device(sub.frames, sync=True, save_logits=self._save, want_visual=sub.outs[3] is not None, **self._kw)
+            sub.outs = r
+            return extract()
+
+        self._done = self._deliver(extract, self._out_device.type == "cpu", rerun)
+        return self._done
 
 
 def _rebuild(cfg_dict, weights, kwargs):
@@ -175,7 +244,7 @@ class GitCaptioner(nn.Module):
             self.poll_errors()
             return out
         except _lib.GitcapExchangeTimeout:
-            self._inflight.clear()
+            self._poison_inflight()          # their ids are undefined: each future re-runs its batch when asked for its result
             out = produce()
             self.poll_errors()
             return out
@@ -185,13 +254,20 @@ class GitCaptioner(nn.Module):
         """Make the current stream wait for a submission (once).  Its frames/ids/steps buffers are owned by the
         model-side table until then: dropping a future early cannot hand them back to the allocator while the
         library's streams still read frames / write ids."""
-        if not sub.waited:
-            with torch.cuda.device(self._dev):
-                self._call("gitcap_greedy_wait", sub.ticket, self._stream())
-            sub.waited = True
-            sub.frames = None
+        if not sub.waited and not sub.poisoned:
+            try:
+                with torch.cuda.device(self._dev):
+                    self._call("gitcap_greedy_wait", sub.ticket, self._stream())
+                sub.waited = True
+            except _lib.GitcapExchangeTimeout:   # raised now, or this ticket was in flight when it was raised: everything
+                self._poison_inflight()          # submitted so far is undefined (the C ABI marks the same tickets)
+                sub.poisoned = True
         if sub in self._inflight:
             self._inflight.remove(sub)
+
+    def _poison_inflight(self):
+        for sub in self._inflight:
+            sub.poisoned = True
 
     def _drain(self):
         """Before a synchronous call: submit what is still waiting to coalesce and order the current stream behind
@@ -344,33 +420,53 @@ class GitCaptioner(nn.Module):
         return self.forward_decoder(y, memory)
 
     @torch.no_grad()
-    def teacher_forward(self, x: torch.Tensor, beam_size: int = 4, max_steps: int = 15) -> list:
+    def teacher_forward(self, x: torch.Tensor, beam_size: int = 4, max_steps: int = 15, on_device: Optional[bool] = None) -> list:
         """``GenerativeImageTextTeacher.forward`` (model.py:762-793): one dict per clip with the keys of
         ``infer`` (model.py:456-461) plus ``cap`` (decoded caption, :770) and ``output`` [1, n, V] = for each of
         the first n predicted words the logits of the beam that scores that word highest (:771-788).
-        The reference runs one clip at a time (:765); here all clips go through ONE batched search and only the
-        per-clip bookkeeping is a loop.  Without a tokenizer ``cap`` is None and n counts the tokens before SEP."""
-        res = self.infer(x, beam_size=beam_size, max_steps=max_steps, save_logits=True, on_device=False)
-        pred, logprobs, saved, vis = res["predictions"], res["logprobs"], res["logits_dict"], res["visual_features"]
+        The reference runs one clip at a time (:765); here the clips go through batched searches (chunks of max_batch, pipelined:
+        the image pass of one chunk overlaps the search of the one before) and only the per-clip bookkeeping is a loop.  Default:
+        the device-resident search with its per-step logits kept on the device (``infer_async``); on_device=False: the host-side
+        operator (one host sync per step).  ``logits_dict`` holds every step's [beams, V] logits; the device search runs all
+        max_steps - 1 steps where the reference stops once the clip is done (:640) -- ``output`` only reads the first n.
+        Without a tokenizer ``cap`` is None and n counts the tokens before SEP."""
+        if on_device is None:
+            on_device = beam_size * 2 <= 16
+        fr = self._frames(x)
+        chunks = []
+        if on_device:
+            futs = [self.infer_async(fr[b0:b0 + self.max_batch], beam_size=beam_size, max_steps=max_steps, save_logits=True,
+                                     visual_features=True) for b0 in range(0, fr.shape[0], self.max_batch)]
+            for f in futs:
+                r = f.result()
+                chunks.append((r["predictions"], r["logprobs"], r["logits_dict"], r["visual_features"]))
+        else:
+            for b0 in range(0, fr.shape[0], self.max_batch):
+                r = self.infer(fr[b0:b0 + self.max_batch], beam_size=beam_size, max_steps=max_steps, save_logits=True, on_device=False)
+                steps = torch.from_numpy(np.stack([np.asarray(st) for st in r["logits_dict"]])).to(self._dev)
+                chunks.append((r["predictions"], r["logprobs"], steps, r["visual_features"]))
         out = []
-        for b in range(pred.shape[0]):
-            logits_b = [np.asarray(st[b * beam_size:(b + 1) * beam_size]) for st in saved]     # per step [beams, V]
-            ids = pred[b].tolist()
-            if self.tokenizer is not None:
-                cap = self.tokenizer.decode(ids, skip_special_tokens=True)
-                n = min(len(cap.split(" ")), len(logits_b))                                     # model.py:771
-            else:
-                cap = None
-                body = ids[1:]
-                n = min(body.index(self.sep_token_id) if self.sep_token_id in body else len(body), len(logits_b))
-            n = max(n, 1)
-            dist = torch.from_numpy(np.stack(logits_b[:n])).to(self._dev)                       # [n, beams, V]
-            words = pred[b, 1:n + 1].to(self._dev)
-            at_word = torch.gather(dist, 2, words[:, None, None].expand(-1, beam_size, -1)).squeeze(-1)   # [n, beams]
-            best = at_word.argmax(dim=1)                                                        # model.py:785
-            output = torch.gather(dist, 1, best[:, None, None].expand(-1, -1, dist.shape[-1])).squeeze(1)[None]
-            out.append({"predictions": pred[b:b + 1], "logprobs": logprobs[b:b + 1], "logits_dict": logits_b,
-                        "visual_features": vis[b:b + 1], "output": output, "cap": cap})
+        for pred, logprobs, steps, vis in chunks:                                # steps: [S, Bc * beams, V] on the device
+            pred_h = pred.cpu()
+            for b in range(pred.shape[0]):
+                dist_all = steps[:, b * beam_size:(b + 1) * beam_size]              # [S, beams, V]
+                ids = pred_h[b].tolist()
+                if self.tokenizer is not None:
+                    cap = self.tokenizer.decode(ids, skip_special_tokens=True)
+                    n = min(len(cap.split(" ")), dist_all.shape[0])                 # model.py:771
+                else:
+                    cap = None
+                    body = ids[1:]
+                    n = min(body.index(self.sep_token_id) if self.sep_token_id in body else len(body), dist_all.shape[0])
+                n = max(n, 1)
+                dist = dist_all[:n]                                                 # [n, beams, V]
+                words = pred[b, 1:n + 1].to(self._dev)
+                at_word = torch.gather(dist, 2, words[:, None, None].expand(-1, beam_size, -1)).squeeze(-1)   # [n, beams]
+                best = at_word.argmax(dim=1)                                        # model.py:785
+                output = torch.gather(dist, 1, best[:, None, None].expand(-1, -1, dist.shape[-1])).squeeze(1)[None]
+                out.append({"predictions": pred[b:b + 1], "logprobs": logprobs[b:b + 1],
+                            "logits_dict": [a for a in dist_all.cpu().numpy()],
+                            "visual_features": vis[b:b + 1], "output": output, "cap": cap})
         return out
 
     @torch.no_grad()
@@ -495,7 +591,7 @@ class GitCaptioner(nn.Module):
                        ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(steps.data_ptr()), self._stream(),
                        ctypes.byref(ticket))
         self._last_memory = None
-        shared = _Submission(ticket.value, ids, steps, frames, len(group) > 1)
+        shared = _Submission(ticket.value, frames, (ids, steps), len(group) > 1, users=len(group))
         self._inflight.append(shared)
         r0 = 0
         for f in group:
@@ -540,21 +636,12 @@ class GitCaptioner(nn.Module):
             on_device = (num_keep_best == 1 and not save_logits and beam_size * per_node_beam_size <= 16
                          and per_node_beam_size >= 2)
         if on_device:
-            if per_node_beam_size < 2:
-                raise ValueError("the device-resident search needs per_node_beam_size >= 2: with one candidate per beam "
-                                 "a single EOS leaves fewer than beam_size live beams (model.py:606 asserts against it); "
-                                 "the host operator (on_device=False) raises when that happens")
-            # the whole search on the GPU, no per-step host sync (gitcap_beam_search)
-            if num_keep_best != 1 or save_logits:
-                raise ValueError("the device-resident search keeps one hypothesis and does not export per-step logits")
-            decoded = torch.empty((B, max_steps), dtype=torch.int64, device=self._dev)
-            logprobs = torch.empty((B,), dtype=torch.float32, device=self._dev)
-            with torch.cuda.device(self._dev):
-                self._call("gitcap_beam_search", ctypes.c_void_p(fr.data_ptr()), B, F, beam_size, max_steps,
-                           ctypes.c_float(length_penalty), per_node_beam_size, ctypes.c_void_p(decoded.data_ptr()),
-                           ctypes.c_void_p(logprobs.data_ptr()), self._stream())
-            self._last_memory = None
-            return {"predictions": decoded, "logprobs": logprobs[:, None], "logits_dict": [], "visual_features": None}
+            self._check_device_search(beam_size, per_node_beam_size, num_keep_best)
+            decoded, logprobs, steps, vis = self._infer_device(fr, beam_size=beam_size, max_steps=max_steps, length_penalty=length_penalty,
+                                                               per_node_beam_size=per_node_beam_size, sync=True,
+                                                               save_logits=save_logits, want_visual=False)
+            return {"predictions": decoded, "logprobs": logprobs[:, None], "logits_dict": [] if steps is None else steps,
+                    "visual_features": None}
         _, vis = self.forward_image_enc(fr)
         searcher = GeneratorWithBeamSearch(self.sep_token_id, max_steps, beam_size, per_node_beam_size, length_penalty)
         start = torch.full((B, 1), self.cls_token_id, dtype=torch.long, device=self._dev)      # model.py:429-431
@@ -568,6 +655,71 @@ class GitCaptioner(nn.Module):
         decoded, logprobs, saved = searcher.search(start, step, num_keep_best=num_keep_best, reorder=reorder,
                                                    save_logits=save_logits)
         return {"predictions": decoded, "logprobs": logprobs, "logits_dict": saved, "visual_features": vis}
+
+    def _check_device_search(self, beam_size, per_node_beam_size, num_keep_best):
+        if per_node_beam_size < 2:
+            raise ValueError("the device-resident search needs per_node_beam_size >= 2: with one candidate per beam "
+                             "a single EOS leaves fewer than beam_size live beams (model.py:606 asserts against it); "
+                             "the host operator (on_device=False) raises when that happens")
+        if num_keep_best != 1:
+            raise ValueError("the device-resident search keeps one hypothesis")
+        if beam_size * per_node_beam_size > 16:
+            raise ValueError("the device-resident search ranks at most 16 candidates per clip")
+
+    def _infer_device(self, fr, *, beam_size, max_steps, length_penalty, per_node_beam_size, sync, save_logits, want_visual):
+        """The device-resident search on frames already staged: synchronously on the current stream (sync=True; per-step logits
+        are not available there) or as a pipelined submission.  Returns (decoded, logprobs, step logits | None, visual | None)
+        [+ the ticket when submitted]."""
+        B, F = fr.shape[:2]
+        decoded = torch.empty((B, max_steps), dtype=torch.int64, device=self._dev)
+        logprobs = torch.empty((B,), dtype=torch.float32, device=self._dev)
+        null = ctypes.c_void_p(None)
+        with torch.cuda.device(self._dev):
+            if sync and not save_logits and not want_visual:
+                self._drain()
+                self._call("gitcap_beam_search", ctypes.c_void_p(fr.data_ptr()), B, F, beam_size, max_steps,
+                           ctypes.c_float(length_penalty), per_node_beam_size, ctypes.c_void_p(decoded.data_ptr()),
+                           ctypes.c_void_p(logprobs.data_ptr()), self._stream())
+                self._last_memory = None
+                return decoded, logprobs, None, None
+            steps = torch.empty((max_steps - 1, B * beam_size, self.cfg.vocab_size), dtype=torch.float32, device=self._dev) if save_logits else None
+            vis = torch.empty((B, F * self.cfg.tokens_per_frame, self.cfg.enc_width), dtype=torch.float32, device=self._dev) if want_visual else None
+            while len(self._inflight) >= 4:
+                self._wait_submission(self._inflight[0])
+            ticket = ctypes.c_int(-1)
+            self._call("gitcap_beam_search_submit", ctypes.c_void_p(fr.data_ptr()), B, F,
+                       ctypes.c_void_p(vis.data_ptr()) if want_visual else null, beam_size, max_steps, ctypes.c_float(length_penalty),
+                       per_node_beam_size, ctypes.c_void_p(decoded.data_ptr()), ctypes.c_void_p(logprobs.data_ptr()),
+                       ctypes.c_void_p(steps.data_ptr()) if save_logits else null, self._stream(), ctypes.byref(ticket))
+            self._last_memory = None
+            if sync:                           # (a re-run, or a synchronous call that wants logits / visual features)
+                self._call("gitcap_beam_search_wait", ticket.value, self._stream())
+                return decoded, logprobs, steps, vis
+        return decoded, logprobs, steps, vis, ticket.value
+
+    @torch.no_grad()
+    def infer_async(self, src: torch.Tensor, beam_size: int = 4, max_steps: int = 15, length_penalty: float = 0.6,
+                    per_node_beam_size: int = 2, save_logits: bool = False, visual_features: bool = False) -> "InferFuture":
+        """Pipelined ``infer`` (the device-resident search) for a stream of batches: returns at once with a future; up to FOUR
+        submissions (of this kind or of greedy_decode_async) may be in flight, so one batch's image pass overlaps the search loops
+        of the batches before it.  ``result()`` returns ``infer``'s dict; with ``save_logits`` its ``logits_dict`` is one device
+        tensor [max_steps - 1, B * beam_size, V] (the raw logits of every step, model.py:521), with ``visual_features`` the fp32
+        features [B, F*N, Dv] (model.py:460).  Results are bitwise those of the synchronous call."""
+        self._check_device_search(beam_size, per_node_beam_size, 1)
+        if beam_size > self.max_beams:
+            raise ValueError(f"beam_size {beam_size} > max_beams={self.max_beams} the handle was created for")
+        if max_steps > self.max_text_len:
+            raise ValueError(f"max_steps {max_steps} > max_text_len={self.max_text_len}")
+        if self._pending:
+            self._flush_pending()
+        fr = self._frames(src)
+        if fr.shape[0] > self.max_batch:
+            raise ValueError(f"batch {fr.shape[0]} > max_batch={self.max_batch}")
+        kw = dict(beam_size=beam_size, max_steps=max_steps, length_penalty=length_penalty, per_node_beam_size=per_node_beam_size)
+        decoded, logprobs, steps, vis, ticket = self._infer_device(fr, sync=False, save_logits=save_logits, want_visual=visual_features, **kw)
+        sub = _Submission(ticket, fr, (decoded, logprobs, steps, vis), False)
+        self._inflight.append(sub)
+        return InferFuture(self, sub, kw, src.device, save_logits)
 
     def beam_search(self, src: torch.Tensor, max_len: int = 10, k: int = 3) -> torch.Tensor:
         """Signature of StudentCandidateV1.beam_search (model.py:189): best sequence per clip

@@ -102,20 +102,32 @@ def synthetic_weights(cfg: GitCapConfig, seed: int = 0, head_gain: float = 4.0) 
     return out
 
 
-def stress_weights(cfg: GitCapConfig, seed: int = 0, head_gain: float = 4.0) -> Dict[str, np.ndarray]:
+def stress_weights(cfg: GitCapConfig, seed: int = 0, head_gain: float = 4.0, gamma_gain: float = 20.0,
+                   qk_gain: float = 3.0, fc1_gain: float = 30.0, row_gain: float = 10.0,
+                   dec_gamma_gain: float = 5.0, enc_qk_gain: float = 2.0) -> Dict[str, np.ndarray]:
     """``synthetic_weights`` + the statistics trained CLIP / GIT checkpoints are known for and i.i.d. weights lack
     (second weight family of the parity tests; fixtures tests/golden/hf_*_stress.npz):
 
-      * outlier channels: LayerNorm gamma x 20 on 4 channels of ``enc.ln_pre`` and of every ``ln2`` (encoder: the FC1
-        operand; decoder: the layer output, i.e. the next q|k|v operand and the head operand);
+      * outlier channels: LayerNorm gamma x 20 on 4 channels of ``enc.ln_pre`` and of every encoder ``ln2`` (the FC1
+        operand: values of +-60 next to O(1) ones), x 5 on 4 channels of every decoder ``ln2`` (the layer output: the next
+        q|k|v operand, the residual stream and the head operand; the head's columns for them are divided by the same
+        factor, as the consumer of an outlier channel is in a trained model);
       * saturating GELU inputs: the FC1 rows of two hidden units of every layer x 30 (pre-activations of std ~ 24, GELU /
         QuickGELU outputs far beyond the +-28 the default e4m3 activation scale of compute="fp8_ffn" covers; data
-        dependent, as in trained models -- a constant FC1 bias of + 30 adds the same vector to every row and the captions
-        collapse to one repeated token);
+        dependent -- a constant FC1 bias of + 30 adds the same vector to every row and the captions collapse to one
+        repeated token);
       * large-norm rows: the CLS embedding, position row 0 and two more position rows of the encoder x 10, text position
         rows 0 and 1 x 10;
-      * a peaked head: q and k of head 0 x 4 in every attention (scores x 16: near one-hot softmax rows, the online-softmax
-        rescale and the text kernel's partial-state merge on hard cases).
+      * a peaked head: q and k of head 0 x 3 in every decoder attention (scores x 9), x 2 in the encoder (scores x 4):
+        softmax rows dominated by a few keys, maxima that move by tens of units between key blocks (the online-softmax
+        rescale of attention.hip, the partial-state merge of txtblock.hip).
+
+    The gains are as large as the model stays WELL CONDITIONED for: what the fixtures must expose is a kernel that mishandles
+    large magnitudes, not the chaos of a random network.  Measured at GIT-base (2 frames, 6 text positions), max |logit
+    difference| between the fp32 oracle and the oracle with the device's bf16 rounding points: plain weights 0.12; these
+    defaults 0.46; decoder q,k x 4 instead of x 3: 1.65; decoder gamma x 20: 1.9; everything at the first-draft gains
+    (gamma x 20 everywhere, q,k x 4 everywhere): 7.6 on logits of std 4 -- winner-take-all attention rows over 394 random
+    keys flip their winner under a bf16 rounding of q, and the comparison says nothing about the kernels any more.
     """
     w = synthetic_weights(cfg, seed, head_gain)
     w = {k: v.copy() for k, v in w.items()}
@@ -124,26 +136,26 @@ def stress_weights(cfg: GitCapConfig, seed: int = 0, head_gain: float = 4.0) -> 
     def chans(name, n, width):
         return _rng(seed, "stress:" + name).choice(width, size=n, replace=False)
 
-    w["enc.ln_pre.w"][chans("enc.ln_pre", 4, Dv)] *= 20.0
+    w["enc.ln_pre.w"][chans("enc.ln_pre", 4, Dv)] *= gamma_gain
     for i in range(cfg.enc_layers):
         p = f"enc.L{i}."
-        w[p + "ln2.w"][chans(p + "ln2", 4, Dv)] *= 20.0
-        w[p + "fc1.w"][chans(p + "fc1", 2, cfg.enc_ffn)] *= 30.0
-        w[p + "qkv.w"][0:64] *= 4.0
-        w[p + "qkv.w"][Dv:Dv + 64] *= 4.0
+        w[p + "ln2.w"][chans(p + "ln2", 4, Dv)] *= gamma_gain
+        w[p + "fc1.w"][chans(p + "fc1", 2, cfg.enc_ffn)] *= fc1_gain
+        w[p + "qkv.w"][0:64] *= enc_qk_gain
+        w[p + "qkv.w"][Dv:Dv + 64] *= enc_qk_gain
     for i in range(cfg.dec_layers):
         p = f"dec.L{i}."
         oc = chans(p + "ln2", 4, D)
-        w[p + "ln2.w"][oc] *= 20.0
-        if i + 1 == cfg.dec_layers:      # the head reads these rows: as in trained models, the consumer of an outlier channel
-            w["head.w"][:, oc] /= 20.0   # carries small weights for it (the logits keep their spread; captions stay varied)
-        w[p + "fc1.w"][chans(p + "fc1", 2, cfg.dec_ffn)] *= 30.0
-        w[p + "qkv.w"][0:64] *= 4.0
-        w[p + "qkv.w"][D:D + 64] *= 4.0
-    w["enc.cls"] *= 10.0
+        w[p + "ln2.w"][oc] *= dec_gamma_gain
+        if i + 1 == cfg.dec_layers:               # the head reads these rows: as in trained models, the consumer of an outlier channel
+            w["head.w"][:, oc] /= dec_gamma_gain  # carries small weights for it (the logits keep their spread; captions stay varied)
+        w[p + "fc1.w"][chans(p + "fc1", 2, cfg.dec_ffn)] *= fc1_gain
+        w[p + "qkv.w"][0:64] *= qk_gain
+        w[p + "qkv.w"][D:D + 64] *= qk_gain
+    w["enc.cls"] *= row_gain
     N = cfg.tokens_per_frame
-    w["enc.pos"][[0, N // 3, N - 1]] *= 10.0
-    w["txt.pos"][[0, 1]] *= 10.0
+    w["enc.pos"][[0, N // 3, N - 1]] *= row_gain
+    w["txt.pos"][[0, 1]] *= row_gain
     return w
 
 
