@@ -230,6 +230,16 @@ class GitCaptioner(nn.Module):
         rc = getattr(self._lib, name)(self._handle, *args)
         _lib.check(self._lib, self._handle, rc, name)
 
+    def _submit(self, name, *args):
+        """A gitcap_*_submit call.  If the library reports a failed statistics exchange at this entry (GITCAP_ERR_EXCHANGE, once)
+        nothing was submitted: everything already in flight is undefined (marked; each future re-runs its batch when asked) and the
+        call is repeated on the handle, which has switched to the unfused launches."""
+        try:
+            self._call(name, *args)
+        except _lib.GitcapExchangeTimeout:
+            self._poison_inflight()
+            self._call(name, *args)
+
     def poll_errors(self):
         """Raises GitcapExchangeTimeout if a fused GEMM + LayerNorm launch gave up waiting since the last check
         (gitcap_poll_errors, include/gitcap.h).  Meaningful after the stream that produced a result was synchronised."""
@@ -586,7 +596,7 @@ class GitCaptioner(nn.Module):
             ids = torch.empty((B, max_len + 1), dtype=torch.int64, device=self._dev)
             steps = torch.zeros((1,), dtype=torch.int32, device=self._dev)
             ticket = ctypes.c_int(-1)
-            self._call("gitcap_greedy_submit", ctypes.c_void_p(frames.data_ptr()), B, F, max_len,
+            self._submit("gitcap_greedy_submit", ctypes.c_void_p(frames.data_ptr()), B, F, max_len,
                        STOP_NEVER if len(group) > 1 else mode,       # the stop rule is per caller batch: applied in result()
                        ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(steps.data_ptr()), self._stream(),
                        ctypes.byref(ticket))
@@ -687,7 +697,7 @@ class GitCaptioner(nn.Module):
             while len(self._inflight) >= 4:
                 self._wait_submission(self._inflight[0])
             ticket = ctypes.c_int(-1)
-            self._call("gitcap_beam_search_submit", ctypes.c_void_p(fr.data_ptr()), B, F,
+            self._submit("gitcap_beam_search_submit", ctypes.c_void_p(fr.data_ptr()), B, F,
                        ctypes.c_void_p(vis.data_ptr()) if want_visual else null, beam_size, max_steps, ctypes.c_float(length_penalty),
                        per_node_beam_size, ctypes.c_void_p(decoded.data_ptr()), ctypes.c_void_p(logprobs.data_ptr()),
                        ctypes.c_void_p(steps.data_ptr()) if save_logits else null, self._stream(), ctypes.byref(ticket))
