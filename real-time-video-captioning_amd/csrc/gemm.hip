@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
         // a bare s_barrier: __syncthreads() is a fence too, and for the fence the compiler waits with vmcnt(0) -- for the tiles that
         // were just requested, which made every k-tile cost a full LDS-DMA round trip whatever NST (tools/isa_waits.py).  The counted
         // wait above is what orders this wave's DMA; the barrier publishes every wave's pieces and retires the previous tile's reads.
-        asm volatile("" ::: "memory");
+        // (lgkmcnt(0): the previous tile's fragment reads have been consumed by its MFMAs, so the wait is free; it makes the
+        // write-after-read order of the LDS-DMA issued below independent of where the compiler places its own waits)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (t + NST - 1 < nt) stage((t + NST - 1) % NST, (t + NST - 1) * BK);

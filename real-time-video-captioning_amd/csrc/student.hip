@@ -564,7 +564,8 @@ int gitcap_student_beam_search(gitcap_student_t* h, const float* memory, int B, 
     for (int t = 0; t + 1 < max_len && !rc; ++t) {                      // the token at position t is decoded, position t + 1 chosen
         if (t > 0) {                                                    // rows continue beam src_rows[r]: positions 0 .. t-1, all layers
             bf16_t* other = h->kvs == kvs_home ? w.kvs2 : kvs_home;
-            S_HIP_OK(h, launch_gather_txt_rows(h->kvs, other, w.src_rows, rows, t, h->Tmax, 3 * D, h->L, kv_layer, s));
+            const hipError_t eg = launch_gather_txt_rows(h->kvs, other, w.src_rows, rows, t, h->Tmax, 3 * D, h->L, kv_layer, s);
+            if (eg != hipSuccess) { rc = sfail(h, GITCAP_ERR_HIP, std::string("student_beam_search: gather_txt_rows: ") + hipGetErrorString(eg)); break; }   // (h->kvs is restored below on every path)
             h->kvs = other;
         }
         rc = text_forward(h, cur, ld, rows, t, 1, w.logits, nullptr, 0, nullptr, 0, s);

@@ -11,11 +11,27 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") and shutil.which("hipcc") is None, reason="needs hipcc")
+# The expectations below (wait sequences, scratch bytes) describe the output of ONE compiler: they were taken with the hipcc of
+# ROCm 7.2 (HIP version 7.2.x).  On another major.minor the module is SKIPPED, not failed: a different schedule is then a reason
+# to re-read the listings (tools/isa_waits.py) and re-take the expectations, not a defect of the source.  The compile flags are
+# read from csrc/Makefile (tools/isa_waits.py: product_flags), so what is linted is what is shipped.
+EXPECTED_HIPCC = "7.2"
+
+
+def _hipcc_ok():
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        return False, "needs /opt/rocm/bin/hipcc"
+    from isa_waits import hipcc_version
+    v = hipcc_version()
+    return v == EXPECTED_HIPCC, f"ISA expectations were taken with hipcc {EXPECTED_HIPCC}, this is {v}: re-take them (tools/isa_waits.py)"
+
+
+_ok, _why = _hipcc_ok()
+pytestmark = pytest.mark.skipif(not _ok, reason=_why)
 
 # kernels that are allowed a few dwords of scratch (the residual + LayerNorm epilogue of the 256 x 256 tile at 256 VGPRs), in bytes
 # (ILi6ELb1 / ILi7ELb1: the opt-in fp8-compute instantiations that also write and count the e4m3 copy of the LayerNorm output)
-SCRATCH_ALLOWED = {"gemm256_kernelILi6ELb0E": 80, "gemm256_kernelILi6ELb1E": 256, "gemm256_kernelILi7ELb1E": 32,
+SCRATCH_ALLOWED = {"gemm256_kernelILi6ELb0E": 80, "gemm256_kernelILi6ELb1E": 80, "gemm256_kernelILi7ELb1E": 32,
                    "gemm256f8_kernelILi6E": 80, "gemm256f8_kernelILi7E": 32}
 FILES = ["attention.hip", "ffn_txt.hip", "gemm.hip", "gemm256.hip", "gemm_f8.hip", "gemm_mt.hip", "preproc.hip", "rowops.hip",
          "skinny.hip", "student.hip", "txtblock.hip"]

@@ -16,13 +16,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "real-time-video-captioning_amd", "csrc")
 
 
-def kernel_listings(src, pat):
+def product_flags():
+    """The compile flags of the product build, read from csrc/Makefile (CXXFLAGS with $(ARCH) / $(EXTRA) resolved to their defaults),
+    so that what is linted is what is shipped."""
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    var = lambda n: re.search(r"^%s[ \t]*\??=[ \t]*(.*)$" % n, mk, re.M).group(1).strip()
+    flags = var("CXXFLAGS").replace("$(ARCH)", var("ARCH")).replace("$(EXTRA)", var("EXTRA"))
+    return [f for f in flags.split() if f not in ("-fPIC", "-Wall", "-Wno-unused-function")]
+
+
+def hipcc_version():
+    """'major.minor' of the HIP compiler (the ISA expectations of tests/test_isa_lint.py were taken on one specific compiler)."""
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout
+    m = re.search(r"HIP version:\s*(\d+)\.(\d+)", out)
+    return "%s.%s" % (m.group(1), m.group(2)) if m else "unknown"
+
+
+def kernel_listings(src, pat, extra_flags=()):
     """[(mangled name, NumVgprs, ScratchSize in bytes, tokens)] of every kernel of `src` whose mangled name contains `pat`."""
     src = src if os.path.exists(src) else os.path.join(CSRC, src)
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
-        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form",
-               "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-S", "--cuda-device-only", "-o", out, src]
+        cmd = ["/opt/rocm/bin/hipcc"] + product_flags() + list(extra_flags) + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-S",
+                                                                             "--cuda-device-only", "-o", out, src]
         subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
         text = open(out).read().splitlines()
     names = [l.split(":")[0] for l in text if re.match(r"^_Z\w+:", l)]
