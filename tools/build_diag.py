@@ -1,7 +1,7 @@
 # Builds tools/libgitcap_diag.so: a copy of csrc/ with s_memtime / s_memrealtime / HW_ID stamps in gemm256
 # (read by tools/gemm_timeline.py through GEMM_DBG_PTR) plus the measured-and-rejected tile kernels of
 # tools/experiments/ (gemm256p.hip: persistent tiles, gemm2b.hip: two workgroups per CU; DESIGN.md "What did not
-# work"), reachable through gitcap_dbg_gemm(tile = 257 | 258).  The product library has neither.
+# work"), reachable through gitcap_dbg_gemm(tile = 259 | 260 | 258).  The product library has neither.
 import os, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tmp = tempfile.mkdtemp(prefix='gitcap_diag_')
@@ -10,11 +10,11 @@ src = os.path.join(ROOT, 'real-time-video-captioning_amd', 'csrc')
 dst = os.path.join(tmp, 'pkg', 'csrc')
 shutil.copytree(src, dst, ignore=shutil.ignore_patterns('build'))
 shutil.copy(os.path.join(ROOT, 'include', 'gitcap.h'), os.path.join(tmp, 'include'))
-for f in ('gemm256p.hip', 'gemm2b.hip'):
+for f in ('gemm256p.hip', 'gemm2b.hip', 'gemm2w.hip'):
     shutil.copy(os.path.join(ROOT, 'tools', 'experiments', f), dst)
 open(os.path.join(dst, 'kernels.h'), 'a').write(
     '\nhipError_t launch_gemm256p(const GemmArgs& a, int epi, hipStream_t s);\nbool gemm2b_ok(const GemmArgs& a);\n'
-    'hipError_t launch_gemm2b(const GemmArgs& a, int epi, hipStream_t s);\n')
+    'hipError_t launch_gemm2b(const GemmArgs& a, int epi, hipStream_t s);\nbool gemm2w_ok(const GemmArgs& a);\nhipError_t launch_gemm2w(const GemmArgs& a, int epi, hipStream_t s);\n')
 def patch(path, pairs):
     s = open(path).read()
     for old, new in pairs:
@@ -37,9 +37,9 @@ patch(os.path.join(dst, 'gemm256.hip'), [
      "        d[6] = R0; d[7] = __builtin_amdgcn_s_memrealtime();\n    }\n"),
 ])
 patch(os.path.join(dst, 'gitcap.hip'), [
-    ("    if (tile != 64 && tile != 128 && tile != 256) return GITCAP_ERR_ARG;\n    hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, (hipStream_t)stream);",
+    ("    if (tile != 64 && tile != 128 && tile != 256 && tile != 224 && tile != 257) return GITCAP_ERR_ARG;\n    hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, (hipStream_t)stream);",
      "    if (getenv(\"GEMM_DBG_PTR\")) a.pos = (const float*)strtoull(getenv(\"GEMM_DBG_PTR\"), nullptr, 0);\n    hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, (hipStream_t)stream);"),
-    ("#ifndef GITCAP_DBG_GEMM_DISPATCH\n", "#define GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, s) ((tile) == 258 ? launch_gemm2b(a, epi, s) : (tile) == 257 ? launch_gemm256p(a, epi, s) : (tile) == 256 ? launch_gemm256(a, epi, s) : (tile) == 64 ? launch_gemm64(a, epi, s) : launch_gemm(a, epi, s))\n#ifndef GITCAP_DBG_GEMM_DISPATCH\n"),
+    ("#ifndef GITCAP_DBG_GEMM_DISPATCH\n", "#define GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, s) ((tile) == 258 ? launch_gemm2w(a, epi, s) : (tile) == 260 ? launch_gemm2b(a, epi, s) : (tile) == 259 ? launch_gemm256p(a, epi, s) : (tile) == 256 ? launch_gemm256(a, epi, s) : (tile) == 64 ? launch_gemm64(a, epi, s) : (tile) == 224 ? launch_gemm_mt(a, epi, 224, s) : (tile) == 257 ? launch_gemm_mt(a, epi, 256, s) : launch_gemm(a, epi, s))\n#ifndef GITCAP_DBG_GEMM_DISPATCH\n"),
 ])
 srcs = 'SRCS=' + ' '.join(sorted(f for f in os.listdir(dst) if f.endswith('.hip')))
 subprocess.check_call(['make', '-C', dst, '-j8', srcs])
