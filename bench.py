@@ -489,7 +489,7 @@ def main():
     roofline, breakdown = None, None
     if not args.no_profile and not args.plain:
         # The brackets need one batch at a time (synchronous calls).  Synchronous calls would take 224-row GEMM tiles
-        # (a latency lever the pipelined submissions do not use: DESIGN.md par. 6), so that switch is turned off for this
+        # (a latency lever the pipelined submissions do not use: docs/LAB_NOTEBOOK.md par. 6), so that switch is turned off for this
         # pass: what is bracketed is gemm256_kernel, the kernel the timed (pipelined) region above ran.
         old224 = model._lib.gitcap_dbg_config(4, 0)
         model.profile(True)

@@ -92,7 +92,7 @@ int gitcap_set_weight_storage(gitcap_t* h, int storage);
  * image rows run on v_mfma_f32_16x16x128_f8f6f4 with the e4m3 weight codes read as stored and activations quantised to e4m3 with a
  * static scale (default: codes of value * 16, saturating at +-28; gitcap_set_fp8_scale / gitcap_fp8_saturations below) by the
  * producing epilogues; everything else stays bf16.  Results differ from
- * bf16 compute by the activation rounding (measured |dlogit| <= 0.3 of a spread of 4 on GIT-large: DESIGN.md par. 3 / 6); the oracle's
+ * bf16 compute by the activation rounding (measured |dlogit| <= 0.3 of a spread of 4 on GIT-large: docs/LAB_NOTEBOOK.md par. 3 / 6); the oracle's
  * counterpart is GitOracle(emulate_fp8_act="ffn"). */
 enum { GITCAP_COMPUTE_BF16 = 0, GITCAP_COMPUTE_FP8_FFN = 1 };
 int gitcap_set_compute(gitcap_t* h, int compute);

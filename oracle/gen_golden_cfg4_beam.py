@@ -1,7 +1,7 @@
 """Golden vector for BASELINE configs[4] that a device must reproduce EXACTLY.  TEST INFRASTRUCTURE ONLY.
 
 The configs[4]-shape search case of rounds 2/3 (frame seed 41) parts from the oracle's search at a pruning decision whose
-candidates tie within the bf16 score noise (DESIGN.md par. 3), so it can only be checked margin-gated.  This script looks,
+candidates tie within the bf16 score noise (docs/LAB_NOTEBOOK.md par. 3), so it can only be checked margin-gated.  This script looks,
 on the CPU and with the oracle alone, for a clip whose CAPTION cannot depend on such ties: GIT-large (ViT-L/14; teacher
 config /root/reference/data/teacher_configs/GIT_LARGE_MSRVTT/parameter.yaml:1-3), 10 frames, e4m3-valued weights (the very
 weights of test_config4_real_shape_fp8_beam), beam 4, 15 steps, length_penalty 0.6 (search defaults

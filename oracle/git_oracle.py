@@ -21,7 +21,7 @@ What this file restates (plain torch fp32, no ``transformers`` import, no refere
     (:73-113 text embeddings, :116-197 attention, :229-290 layer, :343-423 vision embeddings,
      :465-553 vision block, :591-626 tower, :689-699 projection, :796-884 model forward).
 
-``emulate_bf16=True`` reproduces the rounding points of the HIP path:
+``emulate_bf16=True`` reproduces the rounding points of the HIP path (DESIGN.md par. 3):
 GEMM operands (weights and the activations fed to a GEMM, incl. q/k/v, softmax probabilities
 and GELU outputs) are rounded to bf16, everything else (accumulators, residual stream,
 LayerNorm, softmax statistics, embeddings, logits) stays fp32.
@@ -43,7 +43,7 @@ def _r(x: torch.Tensor, on: bool) -> torch.Tensor:
 
 def _q8(x: torch.Tensor) -> torch.Tensor:
     """OCP e4m3 with one power-of-two scale per row (the smallest 2^e with amax / 2^e <= 448; e4m3 x 2^e is a bf16
-    value): the activation encoding of the opt-in fp8-MFMA image pass (csrc: act_quant; DESIGN.md par. 3).  Rounds to
+    value): the activation encoding of the opt-in fp8-MFMA image pass (csrc: act_quant; docs/LAB_NOTEBOOK.md par. 3).  Rounds to
     nearest even, saturates at +-448 x scale (cannot happen: the scale covers the row's amax)."""
     amax = x.abs().amax(dim=-1, keepdim=True).clamp_min(1e-30)
     e = torch.ceil(torch.log2(amax / 448.0))

@@ -57,7 +57,7 @@ __device__ __forceinline__ int count_fp8_clamped(f32x4 c) {
 // 16-byte-chunk XOR swizzle for [rows][64 bf16] (128-B row) LDS tiles read with ds_read_b128 by
 // MFMA operand lanes (row = lane&15 or lane&31, chunk = k/8).  g(row) = (row>>1)&7 makes every
 // ds_read_b128 lane group hit 16 distinct 16-B slots of the 256-B bank row for both the
-// 16x16x32 and the 32x32x16 operand maps (derivation in DESIGN.md, "LDS images").
+// 16x16x32 and the 32x32x16 operand maps (derivation in docs/LAB_NOTEBOOK.md, "LDS images").
 __device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 // XCD-aware bijective block remap (cdna_hip_programming.md T1): blocks that share an XCD

@@ -7,7 +7,7 @@
 // rounds, i.e. 13 % of every GEMM launch is idle CUs.  85 blocks of 224 rows give 255 / 765 / 1020 tiles = 1 / 3 / 4
 // FULL rounds of 7/8 the work each.  The host picks the row count per launch (host_logic.h: pick_tile_rows; gitcap.hip:
 // launch_gemm_auto -- for synchronous calls only: in the pipeline the CUs a 256-row launch leaves idle are what the token
-// loops of the other batches run on, DESIGN.md par. 6); both give the same bits: every output is accumulated over
+// loops of the other batches run on, docs/LAB_NOTEBOOK.md par. 6); both give the same bits: every output is accumulated over
 // ascending k by the same v_mfma_f32_16x16x32_bf16.  Measured per launch: -3 ... -5 % against gemm256.hip at the bench
 // shape (the K loop is 40-60 % of a launch, and this wave layout runs it 1.5-3.5 % slower on equal tiles: the MT = 8
 // instantiation exists for that comparison and for the tests, the product launches MT = 7 only).

@@ -784,7 +784,7 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     }
     if (!rc) {
         // plain non-blocking streams for the pipeline (stream priorities measured neutral and
-        // CU-masked streams 2.5x slower on this platform: DESIGN.md "What did not work")
+        // CU-masked streams 2.5x slower on this platform: docs/LAB_NOTEBOOK.md "What did not work")
         bool ok = hipStreamCreateWithFlags(&h->s_enc, hipStreamNonBlocking) == hipSuccess;
         h->n_txt = g_txt_streams;
         for (int i = 0; i < h->n_txt; ++i) ok = ok && hipStreamCreateWithFlags(&h->txt_streams[i], hipStreamNonBlocking) == hipSuccess;

@@ -1,7 +1,7 @@
 """Parity of the HIP path (through the C ABI) against the CPU oracle and the committed HF-generated
 golden vectors.  Run on the MI355X box:  python -m pytest tests -m gpu -x -q
 
-Numerics contract (DESIGN.md "Numerics"): GEMM operands are bf16 (weights, the activations fed to a
+Numerics contract (DESIGN.md par. 3): GEMM operands are bf16 (weights, the activations fed to a
 GEMM, q/k/v, softmax probabilities, GELU outputs); accumulators, residual stream, LayerNorm,
 softmax statistics, embeddings and logits are fp32.  Tolerances below are stated against
   (a) the oracle run with the SAME rounding points (emulate_bf16=True): differences come only from
@@ -792,7 +792,7 @@ def test_config4_exact_fixture(captioner_cls, golden_dir):
 def test_config4_fp8_ffn_compute(captioner_cls):
     """BASELINE configs[4] at its real shape with compute="fp8_ffn" (FC1 / FC2 of the image rows on fp8 MFMA, e4m3 storage):
     teacher-forced logits against the oracle evaluated with the same e4m3 rounding points, the distance to the bf16-emulating
-    oracle (what the mode costs in accuracy: the 0.3 bar of DESIGN.md par. 6), and the device-resident search against the host
+    oracle (what the mode costs in accuracy: the 0.3 bar of docs/LAB_NOTEBOOK.md par. 6), and the device-resident search against the host
     operator."""
     from gitcap.config import git_large
     from gitcap.weights import quantize_weights_fp8
@@ -815,7 +815,7 @@ def test_config4_fp8_ffn_compute(captioner_cls):
     print(f"configs[4] fp8_ffn: max |dlogit| device vs fp8-emulating oracle {d_own:.3f}, vs bf16-emulating oracle {d_bf16:.3f}, "
           f"fp8 oracle vs bf16 oracle {float((l8 - lb).abs().max()):.3f}")
     assert d_own < 3 * LOGIT_TOL_EMUL, d_own
-    assert d_bf16 < 0.3, d_bf16                  # the accuracy bar of the mode (DESIGN.md par. 3): measured 0.169
+    assert d_bf16 < 0.3, d_bf16                  # the accuracy bar of the mode (docs/LAB_NOTEBOOK.md par. 3): measured 0.169
     # the searches run on the same kernels: device-resident == host operator, bitwise
     out = m.infer(fr, beam_size=4, max_steps=15, length_penalty=0.6, on_device=True)
     host = m.infer(fr, beam_size=4, max_steps=15, length_penalty=0.6, on_device=False)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): SQ counters of attn_full_kernel at S = 197 (ViT frames) and S = 1182 (decoder image
-# prefix) -- is the kernel VALU-issue bound, as its cycle arithmetic says (DESIGN.md par. 6b)?  Separate --pmc passes
+# prefix) -- is the kernel VALU-issue bound, as its cycle arithmetic says (docs/LAB_NOTEBOOK.md par. 6b)?  Separate --pmc passes
 # (8 SQ slots each), kernel trace only.  Summarise with tools/attn_pmc_table.py.
 set -e
 out=gpurun_out/prof_attn_${1:-x}

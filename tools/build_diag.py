@@ -1,6 +1,6 @@
 # Builds tools/libgitcap_diag.so: a copy of csrc/ with s_memtime / s_memrealtime / HW_ID stamps in gemm256
 # (read by tools/gemm_timeline.py through GEMM_DBG_PTR) plus the measured-and-rejected tile kernels of
-# tools/experiments/ (gemm256p.hip: persistent tiles, gemm2b.hip: two workgroups per CU; DESIGN.md "What did not
+# tools/experiments/ (gemm256p.hip: persistent tiles, gemm2b.hip: two workgroups per CU; docs/LAB_NOTEBOOK.md "What did not
 # work"), reachable through gitcap_dbg_gemm(tile = 259 | 260 | 258).  The product library has neither.
 import os, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
