@@ -358,3 +358,36 @@ def test_fp8_ffn_saturation_is_counted_and_scale_is_settable(captioner_cls):
     mb = captioner_cls(cfg, ws, max_batch=3, max_text_len=8, weight_dtype="fp8_e4m3")
     mb.forward_image_enc(fr)
     assert mb.fp8_saturations() == 0                                           # bf16 compute: nothing is ever encoded
+
+
+def test_config4_shape_on_stress_weights(captioner_cls):
+    """BASELINE configs[4]'s shape (GIT-large, 10-frame clip, e4m3-valued weights, beam 4, 15 steps) on the stress family:
+    teacher-forced logits against the bf16-emulating oracle (image half through image_kv), e4m3 storage bitwise equal to bf16
+    storage of the same values, the device-resident search (synchronous and pipelined) bitwise equal to the host operator over
+    the same kernels, and a clip searched alone equal to the same clip inside a batch."""
+    from gitcap.config import git_large
+    cfg = git_large(num_frames=10)
+    wq = quantize_weights_fp8(stress_weights(cfg, 0))
+    fr = make_frames(2, 10, cfg.image_size, 77)
+    m = captioner_cls(cfg, wq, max_batch=2, max_frames=10, max_text_len=16, max_beams=4, weight_dtype="fp8_e4m3")
+    emul, fp32 = GitOracle(cfg, wq, emulate_bf16=True), GitOracle(cfg, wq)
+    ids = torch.tensor([[101, 2023, 2003, 1037, 3899, 2006]])
+    _, vis = m.forward_image_enc(fr[:1])
+    assert float(vis.abs().max()) > 10.0
+    lg = m.forward_decoder(ids, vis).cpu()
+    with torch.no_grad():
+        l_e = emul.decoder_text(emul.image_kv(emul.forward_image_enc(fr[:1])[1]), ids)
+        l_f = fp32.decoder_text(fp32.image_kv(fp32.forward_image_enc(fr[:1])[1]), ids)
+    _check_logits("GIT-large stress", lg, l_e, l_f)
+    mb = captioner_cls(cfg, wq, max_batch=2, max_frames=10, max_text_len=16, max_beams=4, weight_dtype="bf16")
+    _, visb = mb.forward_image_enc(fr[:1])
+    assert torch.equal(visb, vis) and torch.equal(mb.forward_decoder(ids, visb).cpu(), lg)
+    dev = m.infer(fr, beam_size=4, max_steps=15, on_device=True)
+    host = m.infer(fr, beam_size=4, max_steps=15, on_device=False)
+    assert torch.equal(dev["predictions"], host["predictions"])
+    assert torch.allclose(dev["logprobs"].cpu(), host["logprobs"].cpu(), atol=1e-5)
+    futs = [m.infer_async(fr if i != 1 else fr[1:], beam_size=4, max_steps=15) for i in range(3)]
+    res = [f.result() for f in futs]
+    assert torch.equal(res[0]["predictions"], dev["predictions"]) and torch.equal(res[2]["predictions"], dev["predictions"])
+    assert torch.equal(res[1]["predictions"][0], dev["predictions"][1])                 # a clip alone == inside the batch
+    assert torch.equal(mb.infer(fr, beam_size=4, max_steps=15)["predictions"], dev["predictions"])
