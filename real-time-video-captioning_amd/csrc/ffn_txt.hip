@@ -19,18 +19,11 @@
 // launch_skinny(SK_BIAS_GELU_BF16) followed by launch_skinny_splitk(ksplit = F / 64): the same MFMA sequence per
 // element (tests/test_kernels_gpu.py; GITCAP_NO_FFN_FUSE / gitcap_dbg_config(7, 0) selects that pair of launches).
 #include "kernels.h"
-#include "blockln.h"
 #include <type_traits>
 
 namespace {
 
-// ROWS (one or two rows, speed switch 12): the rows are not read from X but computed here -- the reducer tail of the text
-// attention launch (sum of the H per-head output-dense partials + bias + residual, LayerNorm: blockln.h, the reducer's own
-// code, 16 virtual waves of 64 columns so the 4-wave form gives its bits).  Everything the reduce reads is requested first,
-// the weight fragments behind it: the sums and the LayerNorm run while the weights arrive, and the attention launch loses its
-// ticket + reducer tail (3.3 of 13.4 us at one clip).  Both rows are always computed (row 1 repeats row 0 when M = 1: no branch
-// around a load).
-template <int K32, bool FP8, bool ROWS = false>
+template <int K32, bool FP8>
 __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
     constexpr int D = K32 * 32;
     constexpr int NT = (D / 16) / 4;                        // FC2 output tiles (16 columns) per wave
@@ -67,26 +60,7 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
             st[i] = *(const u32x4*)(a.X + (size_t)m * a.ldx + (cs ^ (row & 7)) * 8);
         }
     };
-    // ---- ROWS: everything the reduce of the (two) rows reads, ahead of the weights ----
-    constexpr int NCR = 4, HMAX = 12;
-    float rp[ROWS ? 2 : 1][ROWS ? NCR : 1][ROWS ? HMAX : 1], rxi[ROWS ? 2 : 1][ROWS ? NCR : 1], rg[ROWS ? NCR : 1], rb[ROWS ? NCR : 1], rab[ROWS ? NCR : 1];
-    if (ROWS) {
-#pragma unroll
-        for (int c = 0; c < NCR; ++c) {
-            const int col0 = (int)threadIdx.x + c * 256, col = col0 < D ? col0 : 0;
-            rg[c] = a.ln_g[col]; rb[c] = a.ln_b[col]; rab[c] = a.aob[col];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int m = r < a.M ? r : a.M - 1;
-                rxi[r][c] = a.xin[(size_t)m * D + col];
-                const float* pp = a.part + (size_t)m * a.H * D + col;
-#pragma unroll
-                for (int h = 0; h < HMAX; ++h) rp[r][c][h] = pp[(size_t)(h < a.H ? h : 0) * D];
-            }
-        }
-    } else {
-        gload_x(0);                                         // ahead of the weights: the LDS copy below waits for these alone
-    }
+    gload_x(0);                                             // ahead of the weights: the LDS copy below waits for these alone
 
     // ---- every weight fragment of the wave, requested back to back: 16 hidden rows of W1 (K32 k-steps), then the two
     //      k-steps (hidden 64 s .. + 63) of its NT column tiles of W2
@@ -139,36 +113,7 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
         }
     };
     __builtin_amdgcn_sched_barrier(0);                      // not in front of the weight requests (the copy waits for the rows)
-    if (ROWS) {
-        __shared__ float red[2][16];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            float v[NCR];
-            bool act[NCR];
-#pragma unroll
-            for (int c = 0; c < NCR; ++c) {
-                act[c] = (int)threadIdx.x + c * 256 < D;
-                float sh = 0.f;                             // the reducer's sum: head order, then + (bias + residual)
-#pragma unroll
-                for (int h = 0; h < HMAX; ++h) sh += (h < a.H) ? rp[ROWS ? r : 0][ROWS ? c : 0][ROWS ? h : 0] : 0.f;
-                v[c] = sh + (rab[ROWS ? c : 0] + rxi[ROWS ? r : 0][ROWS ? c : 0]);
-            }
-            float gq[NCR], bq[NCR];
-#pragma unroll
-            for (int c = 0; c < NCR; ++c) { gq[c] = rg[ROWS ? c : 0]; bq[c] = rb[ROWS ? c : 0]; }
-            block_layernorm<NCR>(v, act, D, a.ln_eps, gq, bq, red, (int)threadIdx.x);
-#pragma unroll
-            for (int c = 0; c < NCR; ++c) {
-                const int col = (int)threadIdx.x + c * 256;
-                if (act[c] && r < a.M) {
-                    if (blockIdx.x == 0) a.xf[(size_t)r * D + col] = v[c];
-                    *(bf16_t*)(xs[0] + (4 * K32 * r + ((col >> 3) ^ (r & 7))) * 16 + (col & 7) * 2) = f2bf(v[c]);
-                }
-            }
-        }
-    } else {
-        lstore_x(0);
-    }
+    lstore_x(0);
     // PREFETCH (launches of several m-tiles): the next tile's rows are requested and copied UNCONDITIONALLY (the last tile re-reads
     // itself): a load under a branch is waited for where the branch ends, i.e. at once
     auto do_tile = [&](const int mt, auto prefetch_c) {
@@ -181,12 +126,11 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // ---- FC1 + GELU: h[m][nh .. nh + 3] -> LDS (bf16) ----
-        const int xr = ROWS ? (frow < a.M ? frow : a.M - 1) : frow;       // ROWS: only the valid rows exist in LDS; padded lanes repeat the last
-        const char* xb = xs[mt & 1] + xr * (64 * K32);
+        const char* xb = xs[mt & 1] + frow * (64 * K32);
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < K32; ++k) {
-            const bf16x8 xf = *(const bf16x8*)(xb + (((k * 4 + fq) ^ (xr & 7)) << 4));
+            const bf16x8 xf = *(const bf16x8*)(xb + (((k * 4 + fq) ^ (frow & 7)) << 4));
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[k], xf, acc, 0, 0, 0);
         }
         // the next tile's rows: in flight under GELU, FC2 and the stores
@@ -219,7 +163,7 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
     // Pairs: the second tile of a pair is straight-line code behind the first, where the compiler's wait counts are exact.  (Across
     // a loop's back edge its scoreboard merges "the weights may still be arriving" with "12 slab stores are in flight" and the counted
     // waits of the FC1 chain come out as vmcnt(1): from the second iteration on that is a drain of the previous tile's stores.)
-    if (ROWS || mtiles == 1) {
+    if (mtiles == 1) {
         do_tile(0, std::false_type{});
     } else {
         for (int mt = 0; mt < mtiles; mt += 2) {
@@ -234,17 +178,11 @@ __global__ __launch_bounds__(256) void ffn_txt_kernel(FfnTxtArgs a) {
 bool ffn_txt_ok(int D, int F) { return (D == 128 || D == 768) && F > 0 && F % 64 == 0; }
 
 hipError_t launch_ffn_txt(const FfnTxtArgs& a, hipStream_t s) {
-    if (!ffn_txt_ok(a.D, a.F) || a.M <= 0 || (!a.X && !a.part) || !a.W1pk || !a.W2pk || !a.b1 || !a.slabs || (a.ldx & 7) ||
+    if (!ffn_txt_ok(a.D, a.F) || a.M <= 0 || !a.X || !a.W1pk || !a.W2pk || !a.b1 || !a.slabs || (a.ldx & 7) ||
         ((a.w1scale == nullptr) != (a.w2scale == nullptr)))
         return hipErrorInvalidValue;
     const dim3 grid(a.F / 64);
     const bool f8 = a.w1scale != nullptr;
-    if (a.part) {                                           // row prologue: one or two rows, bf16 weights
-        if (f8 || a.M > 2 || a.H <= 0 || a.H > 12 || !a.aob || !a.xin || !a.ln_g || !a.ln_b || !a.xf || a.xf == a.xin) return hipErrorInvalidValue;
-        if (a.D == 768) hipLaunchKernelGGL((ffn_txt_kernel<24, false, true>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((ffn_txt_kernel<4, false, true>), grid, dim3(256), 0, s, a);
-        return hipGetLastError();
-    }
     if (a.D == 768) {
         if (f8) hipLaunchKernelGGL((ffn_txt_kernel<24, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((ffn_txt_kernel<24, false>), grid, dim3(256), 0, s, a);

@@ -522,9 +522,6 @@ std::atomic<bool> g_chain_steps{!env_flag("GITCAP_NO_STEP_CHAIN")};       // git
 // the kernels read the row-major originals; same bits, slower; the FFN then runs as two launches)
 std::atomic<bool> g_wpack{!env_flag("GITCAP_NO_WPACK")};
 std::atomic<bool> g_ffn_fuse{!env_flag("GITCAP_NO_FFN_FUSE")};            // gitcap_dbg_config(7, .): ffn_txt.hip vs FC1 + split-K FC2 launches
-// one / two rows: the attention launch stops at its per-head partials and the FFN launch's prologue reduces + normalises them
-// (ffn_txt.hip ROWS; GITCAP_NO_FFN_ROWS / gitcap_dbg_config(12, 0): the attention launch's own ticket + reducer tail).  Same bits.
-std::atomic<bool> g_ffn_rows{!env_flag("GITCAP_NO_FFN_ROWS")};
 
 bool text_chain_ok(gitcap* h, int rows, int T) {
     return g_chain_steps && T == 1 && !(h->want_hidden && h->cur_slot == 0) &&
@@ -562,7 +559,6 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     // (skinny.hip "row prologue": every workgroup of the q|k|v launch computes the rows itself): 4 launches per layer.
     // The residual rows then alternate between two buffers (workgroup 0 writes them while the others still read the old).
     const bool rows_pro = g_row_prologue && !hid && skinny_row_prologue_ok(M, D, h->dec[0].qkvw.scale != nullptr);
-    const bool ffn_rows = rows_pro && ffn_fused && g_ffn_rows && H <= 12;      // the FFN launch reduces the attention partials itself
     float *xcur = h->xs, *xalt = h->xs2;
     for (int l = 0; l < c.dec_layers; ++l) {
         const DecLayer& L = h->dec[l];
@@ -598,7 +594,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
             ta.kv_img = h->kv_img + (size_t)l * kvi_layer; ta.kv_txt = kvt;
             ta.rows = rows; ta.beams = beams; ta.t0 = t0; ta.T = T; ta.Tmax = h->Tmax; ta.S_img = h->cur_S; ta.H = H; ta.D = D;
             ta.aow = L.aow.p; ta.aowpk = L.aow.scale ? nullptr : L.aow.pk; ta.aoscale = L.aow.scale; ta.aob = L.aob; ta.g1 = L.ln1w; ta.b1 = L.ln1b; ta.xin = xcur; ta.eps = c.dec_ln_eps;
-            ta.part = h->part; ta.cnt = h->row_cnt; ta.xs = xcur; ta.xsb = h->xsb; ta.no_reduce = ffn_rows ? 1 : 0;
+            ta.part = h->part; ta.cnt = h->row_cnt; ta.xs = xcur; ta.xsb = h->xsb;
             // K/V of all layers that one token step streams: beyond what the 256 MiB Infinity Cache can keep next to the
             // 132 MB of decoder weights, the rows are loaded non-temporally (16 clips x 6 frames: 349 MB per step; measured
             // +0.6 % pipelined, -1 % serial step; one clip stays cached across steps and is 4 % faster with the default policy)
@@ -611,12 +607,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
         if (ffn_fused) {
             ProfScope ps(h, GITCAP_PROF_SKINNY, s, 4.0 * M * c.dec_ffn * D, (L.fc1w.scale ? 1.0 : 2.0) * 2.0 * c.dec_ffn * D);
             FfnTxtArgs fa{h->xsb, D, L.fc1w.pk, L.fc2w.pk, L.fc1w.scale, L.fc2w.scale, L.fc1b, M, D, c.dec_ffn, h->slabs};
-            if (ffn_rows) {      // x1 = LayerNorm(sum of the head partials + bias + x0): computed by every FFN workgroup, written once to the other row buffer
-                fa.X = nullptr; fa.part = h->part; fa.H = H; fa.aob = L.aob; fa.xin = xcur; fa.ln_g = L.ln1w; fa.ln_b = L.ln1b;
-                fa.ln_eps = c.dec_ln_eps; fa.xf = xalt;
-            }
             HIP_OK(h, launch_ffn_txt(fa, s));
-            if (ffn_rows) std::swap(xcur, xalt);
         } else {
             if ((rc = skinny(h, s, SK_BIAS_GELU_BF16, h->xsb, D, L.fc1w, L.fc1b, M, c.dec_ffn, D, h->fs, c.dec_ffn))) return rc;
             if ((rc = skinny_splitk(h, s, h->fs, c.dec_ffn, L.fc2w, M, D, c.dec_ffn, h->slabs, ffn_slices ? ks_f : 0))) return rc;
@@ -1434,7 +1425,6 @@ int gitcap_dbg_config(int key, int value) {
         case 9: old = g_txt8.exchange(value != 0); break;
         case 10: old = g_head_share.exchange(value != 0); break;
         case 11: old = g_rows3.exchange(value != 0); break;
-        case 12: old = g_ffn_rows.exchange(value != 0); break;
         default: return GITCAP_ERR_ARG;
     }
     return old;

@@ -120,13 +120,6 @@ struct FfnTxtArgs {
     const float* b1;                            // [F]
     int M, D, F;
     float* slabs;                               // [F / 64][M][D]
-    // Optional row prologue (part != nullptr; M <= 2, bf16 weights): X is not read -- every workgroup computes the rows itself,
-    // x1[m] = LayerNorm(sum_h part[m][h][:] + aob + xin[m]), the reducer tail of the text attention launch (txtblock.hip, launched
-    // with no_reduce), with the same arithmetic (blockln.h), while its weight fragments are in flight.  Workgroup 0 also writes
-    // the fp32 rows to xf (must not alias xin).
-    const float* part; int H;                   // [M][H][D] per-head partials of the attention output dense
-    const float *aob, *xin, *ln_g, *ln_b; float ln_eps;
-    float* xf;
 };
 bool ffn_txt_ok(int D, int F);
 hipError_t launch_ffn_txt(const FfnTxtArgs& a, hipStream_t s);
@@ -162,7 +155,6 @@ struct TxtBlockArgs {
     unsigned* cnt;                              // [M] arrival tickets (zero between launches)
     float* xs; bf16_t* xsb;                     // out: x1 [M][D] fp32 and bf16 (xs may alias xin)
     int Mh;                                     // set by the launcher
-    int no_reduce;                              // 1: stop after the per-head partials (the FFN launch's row prologue reduces them)
     int nt_kv;                                  // 1: the K/V rows are streamed with non-temporal loads (they do not fit the caches anyway)
 };
 bool txt_block_ok(int D);

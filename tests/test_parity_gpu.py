@@ -184,7 +184,7 @@ def test_results_do_not_depend_on_speed_switches(captioner_cls):
         return vis.clone(), ids.clone(), m.forward_decoder(ids[:, :-1], vis).clone()
     base8, base1 = run(8), run(1)
     assert torch.equal(base1[1], base8[1][:1]) and torch.equal(base1[0], base8[0][:1])
-    settings = [(0, 0), (1, 0), (2, 1 << 30), (3, 0), (3, 1 << 30), (2, 1), (4, 0), (5, 0), (7, 0), (10, 0), (11, 0), (12, 0)]   # (key, value); (12, 0): one / two rows keep the text attention launch's own reducer tail; (2, 1): 256-tile kernels even for one clip; (4, 0): no 224-row tiles; (5, 0): every token step embeds its own input rows; (7, 0): FC1 and FC2 of the text rows as two launches; (10, 0): the vocabulary head as one single-wave workgroup per tile; (11, 0): the one/two-row prologue's slab reduce in one wave
+    settings = [(0, 0), (1, 0), (2, 1 << 30), (3, 0), (3, 1 << 30), (2, 1), (4, 0), (5, 0), (7, 0), (10, 0), (11, 0)]   # (key, value); (2, 1): 256-tile kernels even for one clip; (4, 0): no 224-row tiles; (5, 0): every token step embeds its own input rows; (7, 0): FC1 and FC2 of the text rows as two launches; (10, 0): the vocabulary head as one single-wave workgroup per tile; (11, 0): the one/two-row prologue's slab reduce in one wave
     for key, value in settings:
         old = lib.gitcap_dbg_config(key, value)
         assert old >= 0
