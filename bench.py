@@ -265,6 +265,7 @@ def other_configs(dev, note):
             if B == 4:
                 rec.update(r)
                 rec["weight_mbytes"] = round(m.weight_bytes() / 1e6, 1)
+                rec["workspace_mbytes"] = round(m.workspace_bytes() / 1e6, 1)      # incl. the fragment-major weight copies
             else:
                 rec[f"B={B}"] = r
         c4[storage] = rec

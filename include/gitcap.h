@@ -284,7 +284,11 @@ int gitcap_dbg_attn_full(const void* qkv, void* ctx, int G, int S, int H, void* 
 int gitcap_dbg_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int D,
                          float* out_f32, void* out_bf16, void* stream);
 
-/* Introspection used by tests and bench.py */
+/* Introspection used by tests and bench.py.  gitcap_weight_bytes counts the tensors as loaded; the fragment-major second copies of
+ * the decoder / head weights that gitcap_finalize_weights makes for the token loop (+132 MB bf16 / +66 MB e4m3 at GIT-base), the
+ * e4m3 staging panels and everything sized by max_batch / max_frames / max_text_len / max_beams are workspace.  The text-row
+ * scratch of the four pipeline slots grows with rows = max_batch * max_beams * max_text_len: 48 fp32 FC2 slabs + 12 per-head
+ * partials per row = 184 KB per row and slot (INTEGRATION.md par. 4 has the formula). */
 int gitcap_workspace_bytes(const gitcap_t* h, int64_t* bytes);
 int gitcap_abi_version(void);
 
