@@ -387,8 +387,10 @@ def test_config4_shape_on_stress_weights(captioner_cls):
     host = m.infer(fr, beam_size=4, max_steps=15, on_device=False)
     assert torch.equal(dev["predictions"], host["predictions"])
     assert torch.allclose(dev["logprobs"].cpu(), host["logprobs"].cpu(), atol=1e-5)
-    futs = [m.infer_async(fr if i != 1 else fr[1:], beam_size=4, max_steps=15) for i in range(3)]
+    futs = [m.infer_async(fr if i != 1 else fr[1:], beam_size=4, max_steps=15) for i in range(3)]      # CPU frames in -> CPU ids out
     res = [f.result() for f in futs]
-    assert torch.equal(res[0]["predictions"], dev["predictions"]) and torch.equal(res[2]["predictions"], dev["predictions"])
-    assert torch.equal(res[1]["predictions"][0], dev["predictions"][1])                 # a clip alone == inside the batch
-    assert torch.equal(mb.infer(fr, beam_size=4, max_steps=15)["predictions"], dev["predictions"])
+    want = dev["predictions"].cpu()
+    assert res[0]["predictions"].device.type == "cpu"
+    assert torch.equal(res[0]["predictions"], want) and torch.equal(res[2]["predictions"], want)
+    assert torch.equal(res[1]["predictions"][0], want[1])                              # a clip alone == inside the batch
+    assert torch.equal(mb.infer(fr, beam_size=4, max_steps=15)["predictions"].cpu(), want)
