@@ -13,7 +13,9 @@
  *   - the caller owns every input/output buffer (device memory unless stated otherwise);
  *     the handle owns weights, KV cache and workspace;
  *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream) and is
- *     asynchronous; nothing here synchronises the device except gitcap_load_tensor/finalize;
+ *     asynchronous; nothing on the data path synchronises the device -- only the set-up and diagnosis calls do
+ *     (gitcap_load_tensor / _finalize_weights, gitcap_set_compute / _set_fp8_scale, gitcap_fp8_saturations, and gitcap_poll_errors
+ *     when it has a failure to report);
  *   - a handle is bound to one device and is not thread-safe.
  */
 #ifndef GITCAP_H

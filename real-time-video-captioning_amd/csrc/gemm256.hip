@@ -310,8 +310,12 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s) {
         case EPI_BIAS_RESID_F32: return launch_t<EPI_BIAS_RESID_F32>(a, s);
         case EPI_BIAS_F32: return launch_t<EPI_BIAS_F32>(a, s);
         case EPI_PATCH_F32: return launch_t<EPI_PATCH_F32>(a, s);
-        // (a.ln_out8: the instantiation that also writes the e4m3 copy of the LayerNorm output, fp8 compute)
-        case EPI_RESID_LN_PRE: return !(gemm256_ln_ok(a) && a.resid) ? hipErrorInvalidValue : a.ln_out8 ? launch_t<EPI_RESID_LN_PRE, true>(a, s) : launch_t<EPI_RESID_LN_PRE>(a, s);
+        // (LN8: the instantiation that can also write the e4m3 copy of the LayerNorm output (a.ln_out8, fp8 compute).  The pre-LN
+        // form ALWAYS takes it: its epilogue runs at the 256-VGPR limit, and without the run-time `if (a.ln_out8)` block in the
+        // normalise loop the register allocator moves its 72 bytes of spills into the residual-add / store loops of phase 1, each
+        // reload behind a vmcnt(0): 52.5 instead of 45.5 us per launch at N = K = 768, 96 instead of 84.6 at 1024
+        // (tools/gemm_ln_ab.py; tests/test_isa_lint.py keeps the spills out of those loops).)
+        case EPI_RESID_LN_PRE: return !(gemm256_ln_ok(a) && a.resid) ? hipErrorInvalidValue : launch_t<EPI_RESID_LN_PRE, true>(a, s);
         case EPI_RESID_LN_POST: return !(gemm256_ln_ok(a) && a.out) ? hipErrorInvalidValue : a.ln_out8 ? launch_t<EPI_RESID_LN_POST, true>(a, s) : launch_t<EPI_RESID_LN_POST>(a, s);
     }
     return hipErrorInvalidValue;

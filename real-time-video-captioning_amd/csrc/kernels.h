@@ -42,9 +42,11 @@ struct GemmArgs {
     const float* wscale; float ascale;
     float out8_inv;               // EPI_BIAS_*GELU_F8: 1 / (static scale of the e4m3 output)
     unsigned char* ln_out8; int ld_ln8; float ln_out8_inv;   // nullable (EPI_RESID_LN_*): e4m3 copy of the LayerNorm output * ln_out8_inv
-    unsigned long long* f8_sat;   // nullable: device counter of e4m3 activation codes (valid rows) the epilogue clamped at +-448
     unsigned* ln_fail;            // nullable: host-visible word raised when a tile gave up waiting for its siblings (no trap)
     unsigned ln_spin_limit;       // polls (~0.3 us each) before giving up; 0 = the default (~30 s)
+    unsigned long long* f8_sat;   // nullable: device counter of e4m3 activation codes (valid rows) the epilogue clamped at +-448
+                                  // (LAST: the residual + LayerNorm epilogue runs at the 256-VGPR limit and where the compiler spills
+                                  // depends on the kernarg layout -- tests/test_isa_lint.py: test_gemm_ln_epilogue_keeps_its_spills_out_of_the_row_loops)
 };
 constexpr unsigned LN_SPIN_DEFAULT = 1u << 26;
 int device_cus();                 // compute units of the current device (cached per device; 256 when the query fails)
