@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void gemm256f8_kernel(GemmArgs a) {
 
     // ---- epilogue through LDS (gemm_epilogue.h; the operand stages are dead after the last barrier) ----
     if (EPI == EPI_RESID_LN_PRE || EPI == EPI_RESID_LN_POST)
-        gemm_epilogue_tile_ln<EPI == EPI_RESID_LN_POST, true>(a, acc, smem, m0, n0, tm, tn, wid, wm, wn, lane);
+        gemm_epilogue_tile_ln<EPI == EPI_RESID_LN_POST, true, EPI == EPI_RESID_LN_PRE>(a, acc, smem, m0, n0, tm, tn, wid, wm, wn, lane);   // (pre-LN: the LN8 form, for its register allocation -- gemm256.hip: launch_gemm256)
     else
         gemm_epilogue_wave<EPI, true>(a, acc, smem + wid * EPI_REGION, m0 + wm * 64, n0 + wn * 128, lane);
 #ifdef LN_STAMPS
