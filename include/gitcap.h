@@ -85,7 +85,10 @@ int gitcap_finalize_weights(gitcap_t* h);
  * the caller's choice: gitcap.weights.quantize_weights_fp8); anything else is refused, nothing is rounded silently.
  * The weight-streaming text kernels read the e4m3 bytes and expand them in registers (times the row scale: exactly the
  * bf16 value); the big-tile GEMMs of the image pass read each panel through a bf16 staging buffer.  Arithmetic is unchanged (bf16 MFMA, fp32 accumulate): results
- * are bitwise those of bf16 storage of the same values. */
+ * are bitwise those of bf16 storage of the same values.  Under bf16 compute this is a CAPACITY option (half the weight bytes in
+ * HBM), not a speed option: the staging launches cost 0.25 ms per BASELINE configs[4] batch (14.1 vs 13.8 ms; pipelined 353 vs 358
+ * captions/s) and the token loop's saving on the weight stream does not make that up at 4 clips x 4 beams; it pays together with
+ * GITCAP_COMPUTE_FP8_FFN below (12.8 ms; pipelined 398 captions/s), whose GEMMs read the codes as stored. */
 typedef enum { GITCAP_W_BF16 = 0, GITCAP_W_FP8_E4M3 = 1 } gitcap_weight_storage;
 int gitcap_set_weight_storage(gitcap_t* h, int storage);
 /* device bytes of all loaded tensors (weights, scales, tables, biases) */
