@@ -14,7 +14,7 @@ def ev(fn, iters=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 M = 18944
-for N, K, epi in [(768, 768, 0), (768, 768, 3), (2304, 768, 0), (3072, 768, 1), (768, 3072, 3), (768, 3072, 0)]:
+for N, K, epi in [(768, 768, 0), (768, 768, 3), (2304, 768, 0), (3072, 768, 0), (3072, 768, 1), (3072, 768, 2), (768, 3072, 3), (768, 3072, 0)]:
     A = torch.randn(M, K, device=dev).bfloat16(); W = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
     bias = torch.randn(N, device=dev); resid = torch.randn(M, N, device=dev) if epi == 3 else None
     out = torch.empty(M, N, device=dev, dtype=torch.float32 if epi == 3 else torch.bfloat16)
