@@ -231,7 +231,7 @@ hipError_t join_async(gitcap* h, hipStream_t stream) {
 int poll_exchange(gitcap* h) {
     if (!h->ln_fail || !exchange_poll(h->xh, *(volatile unsigned*)h->ln_fail)) return 0;
     (void)hipDeviceSynchronize();
-    h->poison_upto = h->next_ticket;            // every submission made so far may hold undefined rows: its wait says so, every time
+    h->poison_upto = poison_mark(h->next_ticket);   // every submission made so far may hold undefined rows: its wait says so, every time
     *(volatile unsigned*)h->ln_fail = 0;
     if (h->ln_cnt) (void)hipMemset(h->ln_cnt, 0, h->ln_cnt_words * sizeof(unsigned));
     return fail(h, GITCAP_ERR_EXCHANGE, "a GEMM + LayerNorm launch timed out waiting for its sibling tiles (CUs held by another "
@@ -1196,7 +1196,7 @@ int gitcap_greedy_wait(gitcap_t* h, int ticket, void* stream) {
     POLL(h);
     if (!ticket_waitable(ticket, h->next_ticket, gitcap::NSLOT))
         return fail(h, GITCAP_ERR_ARG, "greedy_wait: ticket is not one of the submissions in flight");
-    if (ticket < h->poison_upto)
+    if (ticket_poisoned(ticket, h->poison_upto))
         return fail(h, GITCAP_ERR_EXCHANGE, "this submission was in flight when a GEMM + LayerNorm launch timed out waiting for its sibling "
                     "tiles: its results are undefined -- submit it again (the handle now uses separate LayerNorm launches)");
     HIP_OK(h, hipStreamWaitEvent((hipStream_t)stream, h->slots[ticket_slot(ticket, gitcap::NSLOT)].ev_dec, 0));

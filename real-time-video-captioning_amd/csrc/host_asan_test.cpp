@@ -58,6 +58,16 @@ int main() {
     // tickets: four slots, a ticket is waitable until its slot is handed on
     CHECK(ticket_slot(5, 4) == 1 && ticket_waitable(5, 6, 4) && ticket_waitable(2, 6, 4) && !ticket_waitable(1, 6, 4));
     CHECK(!ticket_waitable(6, 6, 4) && !ticket_waitable(-1, 6, 4));
+    // a failed exchange with tickets 3, 4, 5 in flight (next_ticket 6): all of them are refused from then on, ticket 6 (submitted
+    // afterwards, on the unfused launches) is not; a second failure later moves the mark up
+    {
+        int upto = 0;
+        CHECK(!ticket_poisoned(5, upto));
+        upto = poison_mark(6);
+        CHECK(ticket_poisoned(3, upto) && ticket_poisoned(5, upto) && !ticket_poisoned(6, upto) && ticket_waitable(5, 7, 4));
+        upto = poison_mark(9);
+        CHECK(ticket_poisoned(8, upto) && !ticket_poisoned(9, upto));
+    }
     // residual + LayerNorm GEMM: every tile exactly once, a row block's tiles = consecutive workgroups of one XCD
     for (int ntn = 1; ntn <= 4; ++ntn)
         for (int nrb = 1; nrb <= 300; ++nrb) {

@@ -127,6 +127,12 @@ inline int ticket_slot(int ticket, int nslot) { return ticket % nslot; }
 inline bool ticket_waitable(int ticket, int next_ticket, int nslot) {
     return ticket >= 0 && ticket < next_ticket && ticket >= next_ticket - nslot;
 }
+// A failed statistics exchange (ExchangeHealth below) leaves every submission made so far with undefined results: the handle keeps
+// the ticket count at that moment (`poison_upto`), and a wait on a ticket below it is refused every time it is asked for, so a retry
+// cannot hand the ids out (gitcap_greedy_wait / gitcap_beam_search_wait).  Tickets submitted afterwards run on the unfused launches.
+inline int poison_mark(int next_ticket) { return next_ticket; }
+inline bool ticket_poisoned(int ticket, int poison_upto) { return ticket < poison_upto; }
+
 
 // ---- residual + LayerNorm GEMM: workgroup -> tile ----------------------------------------------------------------
 // The N/256 tiles of a 256-row block wait for each other (statistics exchange, gemm_epilogue.h), so they must be
