@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, "/root/reference")
 
 from src.utils.masking import create_casual_mask, create_padding_mask   # noqa: E402  (the reference's helpers)
-from gitcap.student_config import student_base, student_synthetic_weights, student_tiny   # noqa: E402
+from gitcap.student_config import student_base, student_stress_weights, student_synthetic_weights, student_tiny   # noqa: E402
 from oracle.student_oracle import make_memory   # noqa: E402
 
 
@@ -119,6 +119,17 @@ def main():
     top_v, top_i = logits.topk(8, dim=-1)
     np.savez(os.path.join(out_dir, "student_base.npz"), mem_seed=12, greedy_ids=ids.numpy(), top_ids=top_i.numpy(),
              top_vals=top_v.numpy(), first16=logits[:, :, :16].numpy())
+    # ---- the stress family (student_stress_weights: outlier LayerNorm channels, big ReLU inputs, a peaked head), both sizes ----
+    for name, cfg, B, L, seed in (("tiny", student_tiny(), 3, 12, 13), ("base", student_base(), 2, 25, 14)):
+        w = student_stress_weights(cfg, 0)
+        m = TorchStudentDecoder(cfg).eval()
+        m.load(w)
+        mem = make_memory(B, cfg.mem_tokens, cfg.d_model, seed)
+        ids = m.greedy(mem, L, stop_all_sep=False)
+        logits = m.forward_decoder(ids[:, :-1], mem)
+        top_v, top_i = logits.topk(8, dim=-1)
+        np.savez(os.path.join(out_dir, f"student_{name}_stress.npz"), mem_seed=seed, greedy_ids=ids.numpy(), top_ids=top_i.numpy(),
+                 top_vals=top_v.numpy(), first16=logits[:, :, :16].numpy())
     print("wrote student goldens to", out_dir)
 
 

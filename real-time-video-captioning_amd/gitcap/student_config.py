@@ -140,6 +140,29 @@ def student_synthetic_weights(cfg: StudentConfig, seed: int = 0) -> Dict[str, np
     return w
 
 
+def student_stress_weights(cfg: StudentConfig, seed: int = 0, gamma_gain: float = 8.0, fc1_gain: float = 20.0,
+                           qk_gain: float = 3.0) -> Dict[str, np.ndarray]:
+    """``student_synthetic_weights`` + the statistics of trained checkpoints (second weight family of the student decoder's parity
+    tests, the counterpart of gitcap.weights.stress_weights): LayerNorm gamma x 8 on 4 channels of every ``norm3`` (the layer
+    output: the next layer's q|k|v operand, the residual stream, the vocabulary head's operand -- whose columns for the last
+    layer's outlier channels are divided by the same factor), two ``linear1`` rows per layer x 20 (ReLU outputs of tens next to
+    O(1) ones), q and k of head 0 of both attentions x 3 (scores x 9: peaked softmax rows, also over the 6 memory tokens)."""
+    w = {k: v.copy() for k, v in student_synthetic_weights(cfg, seed).items()}
+    rng = np.random.Generator(np.random.PCG64([seed, 0x57e55]))
+    D, hd = cfg.d_model, cfg.d_model // cfg.n_head
+    for i in range(cfg.num_decoder_layers):
+        p = f"decoder.layers.{i}."
+        oc = rng.choice(D, size=4, replace=False)
+        w[p + "norm3.weight"][oc] *= gamma_gain
+        if i + 1 == cfg.num_decoder_layers:
+            w["linear.weight"][:, oc] /= gamma_gain
+        w[p + "linear1.weight"][rng.choice(cfg.d_ffn, size=2, replace=False)] *= fc1_gain
+        for att in ("self_attn", "multihead_attn"):
+            w[p + att + ".in_proj_weight"][0:hd] *= qk_gain
+            w[p + att + ".in_proj_weight"][D:D + hd] *= qk_gain
+    return w
+
+
 def check_student_shapes(cfg: StudentConfig, weights) -> None:
     for name, shape in student_shapes(cfg).items():
         if name not in weights:

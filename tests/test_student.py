@@ -9,8 +9,8 @@ import numpy as np
 import pytest
 import torch
 
-from gitcap.student_config import (student_base, student_shapes, student_synthetic_weights, student_tiny,
-                                   positional_table)
+from gitcap.student_config import (student_base, student_shapes, student_stress_weights, student_synthetic_weights,
+                                   student_tiny, positional_table)
 from oracle.student_oracle import StudentOracle, make_memory
 
 
@@ -63,6 +63,24 @@ def test_base_oracle_matches_torch_decoder(golden_dir):
     assert np.abs(logits[:, :, :16].numpy() - g["first16"]).max() < 1e-4
     margin = g["top_vals"][..., 0] - g["top_vals"][..., 1]
     assert np.array_equal(logits.argmax(-1).numpy()[margin > 1e-3], ids[:, 1:].numpy()[margin > 1e-3])
+
+
+@pytest.mark.parametrize("name", ["tiny", "base"])
+def test_oracle_matches_torch_decoder_on_stress_weights(golden_dir, name):
+    """Second weight family (student_stress_weights: outlier LayerNorm channels, big ReLU inputs, a peaked head) against the
+    torch.nn.TransformerDecoder goldens of oracle/gen_golden_student.py: teacher-forced on the golden ids, top-8 logits per step."""
+    cfg = student_tiny() if name == "tiny" else student_base()
+    g = np.load(os.path.join(golden_dir, f"student_{name}_stress.npz"))
+    orc = StudentOracle(cfg, student_stress_weights(cfg, 0))
+    B = g["greedy_ids"].shape[0]
+    mem = make_memory(B, cfg.mem_tokens, cfg.d_model, int(g["mem_seed"]))
+    ids = torch.from_numpy(g["greedy_ids"])
+    logits = orc.forward_decoder(ids[:, :-1], mem)
+    top = torch.gather(logits, 2, torch.from_numpy(g["top_ids"]))
+    assert np.abs(top.numpy() - g["top_vals"]).max() < 3e-4
+    assert np.abs(logits[:, :, :16].numpy() - g["first16"]).max() < 3e-4
+    margin = g["top_vals"][..., 0] - g["top_vals"][..., 1]
+    assert np.array_equal(logits.argmax(-1).numpy()[margin > 2e-3], ids[:, 1:].numpy()[margin > 2e-3])
 
 
 def test_stop_rule_and_shapes():
@@ -163,6 +181,36 @@ def test_gpu_greedy_kv_cache_and_token_parity(name, golden_dir):
         for b in range(B):
             k = int(same_prefix[b])                 # first divergence, if any, must sit on a near-tie of the golden run
             assert k == gold.shape[1] or margin[b, k - 1] < NEAR_TIE, (b, k, float(margin[b, k - 1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["tiny", "base"])
+def test_gpu_student_on_stress_weights(name, golden_dir):
+    """The student decoder on the stress family: exact KV cache (cached loop == one teacher-forced pass, bitwise), logits against
+    the bf16-emulating oracle (tolerance scaled by what the rounding points cost on this input, as in tests/test_stress_gpu.py)
+    and the torch goldens on the confident steps; beam search device == host form."""
+    cfg = student_tiny() if name == "tiny" else student_base()
+    w = student_stress_weights(cfg, 0)
+    g = np.load(os.path.join(golden_dir, f"student_{name}_stress.npz"))
+    B, L = g["greedy_ids"].shape[0], g["greedy_ids"].shape[1] - 1
+    m = _student(cfg, w, max_batch=3 * B, max_text_len=L)
+    mem = make_memory(B, cfg.mem_tokens, cfg.d_model, int(g["mem_seed"]))
+    ids = m.greedy_decode(mem, max_len=L, stop="never")
+    full = m.forward_decoder(ids[:, :-1], mem).cpu()
+    assert torch.equal(full.argmax(-1), ids[:, 1:])
+    emu = StudentOracle(cfg, w, emulate_bf16=True).forward_decoder(ids[:, :-1], mem)
+    f32 = StudentOracle(cfg, w).forward_decoder(ids[:, :-1], mem)
+    d = float((emu - f32).abs().max())
+    tol = max(TOL_EMU * max(1.0, emu.std().item()), 1.5 * d)
+    print(f"student {name} stress: |emul - fp32| {d:.3f}, device vs emul {float((full - emu).abs().max()):.3f} (tol {tol:.3f})")
+    assert (full - emu).abs().max().item() < tol
+    gold = torch.from_numpy(g["greedy_ids"])
+    margin = torch.from_numpy(g["top_vals"][..., 0] - g["top_vals"][..., 1])
+    same_prefix = (ids == gold).long().cumprod(dim=1).sum(dim=1)
+    for b in range(B):
+        k = int(same_prefix[b])
+        assert k == gold.shape[1] or margin[b, k - 1] < max(NEAR_TIE, 2 * tol), (b, k, float(margin[b, k - 1]))
+    assert torch.equal(m.beam_search(mem, max_len=min(L, 12), k=3), m.beam_search_host(mem, max_len=min(L, 12), k=3))
 
 
 @pytest.mark.gpu
