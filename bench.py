@@ -144,6 +144,62 @@ def cpu_baseline(cfg, weights, runs: int = 20, warmups: int = 3):
             "p50_latency_ms": round(med * 1e3, 1)}
 
 
+def host_fed(model, cfg, dev, note, steps, inflight, resident_value):
+    """The headline workload (configs[2]) with the frames starting in HOST memory, as the reference's callers hold them
+    (src/real_time_inference.py:39-58: OpenCV frames; src/inference.py:27, :45-51: a DataLoader batch, pin_memory=True): every
+    batch crosses PCIe inside the timed region -- through the pinned staging ring and the copy stream of gitcap/model.py
+    (_StagingRing), under the compute of the batches before it.  Never the headline `value` (inputs resident in HBM)."""
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    NIN = 4
+    S = cfg.image_size
+    u8 = [torch.randint(0, 256, (CLIPS_PER_GPU, FRAMES, S, S, 3), dtype=torch.uint8, generator=g) for _ in range(NIN)]
+    f32 = [torch.randn(CLIPS_PER_GPU, FRAMES, 3, S, S, generator=g) for _ in range(NIN)]
+    cases = {
+        "pinned_uint8_hwc_bgr_224": ([x.pin_memory() for x in u8], "uint8 HWC BGR 224x224 camera frames, page-locked; the transform of "
+                                     "dataloader.py:18-32 runs on the device fused with the patch gather (14.5 MB per batch over PCIe)"),
+        "pageable_uint8_hwc_bgr_224": (u8, "the same frames in pageable memory (one parallel copy into the pinned ring first)"),
+        "pinned_fp32_nchw": ([x.pin_memory() for x in f32], "transformed fp32 NCHW frames, page-locked: what DataLoader(pin_memory=True) "
+                             "of src/inference.py:27 yields (57.8 MB per batch over PCIe)"),
+        "pageable_fp32_nchw": (f32, "transformed fp32 NCHW frames in pageable memory (src/utils/dataloader.py:60-82 without pinning)"),
+    }
+    out = {"workload": "BASELINE configs[2] (16 x 6-frame clips, GIT-base, 20 greedy tokens), frames start in host memory; "
+                       f"{inflight} batches in flight, {steps} batches per region, median of 3 regions",
+           "resident_captions_per_s": round(resident_value, 1)}
+    for name, (ins, what) in cases.items():
+        want = [model.greedy_decode(x.to(dev), max_len=TOKENS, stop="never").clone() for x in ins]
+
+        def region(check=False):
+            ev_sub = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+            ev_done = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+            ok, pend = True, []
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                ev_sub[i].record()
+                pend.append((i, model.greedy_decode_async(ins[i % NIN], max_len=TOKENS, stop="never")))
+                if len(pend) == inflight:
+                    j, fut = pend.pop(0)
+                    r = fut.result()                      # CPU in -> CPU out: the ids come back to the host as well
+                    ev_done[j].record()
+                    ok = ok and (not check or bool(torch.equal(r, want[j % NIN].cpu())))
+            for j, fut in pend:
+                r = fut.result()
+                ev_done[j].record()
+                ok = ok and (not check or bool(torch.equal(r, want[j % NIN].cpu())))
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            lat = sorted(ev_sub[i].elapsed_time(ev_done[i]) for i in range(steps))
+            return el, lat[len(lat) // 2], ok
+        same = region(check=True)[2]
+        rs = sorted(region()[:2] for _ in range(3))
+        el, p50 = rs[1]
+        v = CLIPS_PER_GPU * steps / el
+        out[name] = {"what": what, "captions_per_s": round(v, 1), "ms_per_batch": round(el / steps * 1e3, 3), "p50_latency_ms": round(p50, 3),
+                     "fraction_of_resident": round(v / resident_value, 4), "ids_equal_resident_path": same}
+        note(f"host_fed: {name} {v:.0f} captions/s")
+    return out
+
+
 def other_configs(dev, note):
     """The other BASELINE.json configurations and the reference's one real caller, under the same clock as the headline
     (outside its timed region; parity-test cases otherwise): configs[1] (32 single frames, GIT-base), configs[4] (GIT-large,
@@ -210,8 +266,14 @@ def other_configs(dev, note):
     cpu_io = med_ms(lambda: m.greedy_decode(clip, max_len=25, stop="never"), n=9)
     clip_d = clip.to(dev)
     dev20 = med_ms(lambda: m.greedy_decode(clip_d, max_len=TOKENS, stop="never"), n=9)
+    # the same caller before its transform: six 480 x 640 uint8 BGR camera frames (real_time_inference.py:39), pageable host memory,
+    # transform fused into the patch gather on the device
+    cam = torch.randint(0, 256, (1, FRAMES, 480, 640, 3), dtype=torch.uint8, generator=g)
+    cam_io = med_ms(lambda: m.greedy_decode(cam, max_len=25, stop="never"), n=9)
     out["one_clip"] = {"workload": "1 clip x 6 frames, GIT-base; the reference's caller (src/real_time_inference.py:56-58)",
-                       "cpu_in_cpu_out_25_tokens_ms": round(cpu_io, 3), "device_resident_20_tokens_ms": round(dev20, 3)}
+                       "cpu_in_cpu_out_25_tokens_ms": round(cpu_io, 3), "device_resident_20_tokens_ms": round(dev20, 3),
+                       "camera_480x640_uint8_cpu_in_cpu_out_25_tokens_ms": round(cam_io, 3),
+                       "camera_captions_per_s": round(1e3 / cam_io, 1)}
     del m
     note("other_configs: one clip done")
     # ---- configs[4]: GIT-large, 10-frame clips, beam 4, 15 steps, device-resident search; B = 4 / 8 / 16 clips per batch,
@@ -568,8 +630,10 @@ def main():
 
     others = None
     if rank == 0 and world == 1 and not args.plain and not args.no_other_configs:
+        hf = host_fed(model, cfg, dev, note, args.steps, args.inflight, world * CLIPS_PER_GPU * args.steps / elapsed)
         del model
         others = other_configs(dev, note)
+        others["host_fed"] = hf
     note("GPU measurements done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -221,6 +221,20 @@ int gitcap_beam_search_submit(gitcap_t* h, const float* frames, int B, int F, fl
                               int64_t* decoded_out, float* logprobs_out, float* step_logits_out, void* stream, int* ticket);
 int gitcap_beam_search_wait(gitcap_t* h, int ticket, void* stream);
 
+/* The two pipelined submissions for RAW camera frames in device memory (frames_hwc_bgr device uint8 [B][F][H][W][3], as in
+ * gitcap_greedy_raw): the transform of src/utils/dataloader.py:18-32 / src/real_time_inference.py:16-28 fused with the patch
+ * gather runs as the first launch of the image pass on the handle's encoder stream.  This is the form a HOST-fed caller uses
+ * (src/real_time_inference.py:39-58 holds OpenCV frames in host memory; src/inference.py:45-51 a DataLoader's CPU tensor): the
+ * caller copies batch i + 1 to the device on a copy stream of its own (a quarter of the bytes of the fp32 tensor) and passes
+ * THAT stream as `stream`, so the copy runs under batch i's compute and only the image pass waits for it
+ * (gitcap/model.py: _StagingRing is that caller).  Results are bitwise those of gitcap_greedy_raw / of gitcap_preprocess +
+ * gitcap_beam_search.  Tickets, slots and waits as for gitcap_greedy_submit. */
+int gitcap_greedy_raw_submit(gitcap_t* h, const uint8_t* frames_hwc_bgr, int B, int F, int H, int W, int max_len, int stop,
+                             int64_t* ids_out, int32_t* steps_out, void* stream, int* ticket);
+int gitcap_beam_search_raw_submit(gitcap_t* h, const uint8_t* frames_hwc_bgr, int B, int F, int H, int W, float* visual_out,
+                                  int beams, int max_steps, float length_penalty, int per_node_beam_size,
+                                  int64_t* decoded_out, float* logprobs_out, float* step_logits_out, void* stream, int* ticket);
+
 /* Health of the in-kernel statistics exchange (no reference counterpart).  The residual GEMMs that normalise their own output
  * rows exchange LayerNorm statistics between the workgroups of a row block (co-residency).  If a workgroup ever
  * gives up waiting (about 30 s: its siblings cannot become resident because another process or a CU-masked stream holds the
@@ -288,6 +302,13 @@ int gitcap_dbg_attn_full(const void* qkv, void* ctx, int G, int S, int H, void* 
 /* layernorm: x fp32 [rows][D] -> out_f32 / out_bf16 (either may be NULL) */
 int gitcap_dbg_layernorm(const float* x, const float* gamma, const float* beta, float eps, int rows, int D,
                          float* out_f32, void* out_bf16, void* stream);
+
+/* Residual stream of the ViT per block (tests/test_stress_layers_gpu.py: single-block checks on the device's own inputs).
+ * While `buf` is non-NULL every SYNCHRONOUS image pass (gitcap_encode / _greedy / _beam_search and their _raw forms) copies
+ * the fp32 residual stream x [rows][enc_width] (rows = B * F * tokens per frame, unpadded) to buf + e * rows * enc_width:
+ * e = 0 the ln_pre output, e = i the output of encoder block i - 1, for e < enc_layers (the last block's output only exists
+ * behind ln_post: visual_out of gitcap_encode).  buf: device fp32 [enc_layers][rows][enc_width], caller owned; NULL disables. */
+int gitcap_dbg_enc_tap(gitcap_t* h, float* buf);
 
 /* Introspection used by tests and bench.py.  gitcap_weight_bytes counts the tensors as loaded; the fragment-major second copies of
  * the decoder / head weights that gitcap_finalize_weights makes for the token loop (+132 MB bf16 / +66 MB e4m3 at GIT-base), the

@@ -85,6 +85,7 @@ struct gitcap {
     bool want_hidden = false;
     float *hid_img = nullptr, *hid_txt = nullptr;
     int hid_T = 0;
+    float* enc_tap = nullptr;                       // gitcap_dbg_enc_tap: caller's buffer for the ViT's residual stream per block
     int64_t weight_bytes = 0;
 
     // derived sizes
@@ -419,6 +420,8 @@ int gemm_ln(gitcap* h, hipStream_t s, bool post, const bf16_t* A, int lda, const
     a.ln_out8 = ln8; a.ld_ln8 = N; a.ln_out8_inv = 1.0f / h->f8_scale; a.f8_sat = h->f8_sat;
     if (f8in) { a.W = (const bf16_t*)W.p; a.wscale = W.scale; a.ascale = h->f8_scale; }
     const bool force_fused = ln8 != nullptr || f8in;
+    // the e4m3 LayerNorm copy of the fp8-operand kernel exists for the PRE form only (gemm_f8.hip: LN8 = EPI_RESID_LN_PRE)
+    if (f8in && ln8 && post) return fail(h, GITCAP_ERR_STATE, "fp8 compute: no e4m3 LayerNorm copy in the post-LN form of the fp8-operand GEMM");
     a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = eps; a.ln_out = ln_out; a.ld_ln = N; a.ln_stats = h->ln_stats; a.ln_cnt = h->ln_cnt;
     a.ln_stats_rows = h->Mi;
     a.ln_add = addv; a.ln_add_div = add_div; a.ln_add_mod = add_mod; a.ln_out_f32 = ln_f32; a.ld_ln_f32 = N; a.valid_rows = rows;
@@ -477,7 +480,7 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
                       c.proj_ln_eps, rows, h->hb, h->tmp))) return rc;
     const size_t kv_layer = (size_t)h->Mi * 3 * D;
     const bool f8 = use_f8(h);
-    const bool hid = h->want_hidden && h->cur_slot == 0;     // hidden-state export: synchronous path only
+    const bool hid = h->want_hidden && h->cur_slot == 0 && !h->pipelined;     // hidden-state export: synchronous path only
     auto keep = [&](int entry) -> hipError_t {
         return hid ? hipMemcpyAsync(h->hid_img + (size_t)entry * h->Mi * D, h->x, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, s) : hipSuccess;
     };
@@ -524,7 +527,7 @@ std::atomic<bool> g_wpack{!env_flag("GITCAP_NO_WPACK")};
 std::atomic<bool> g_ffn_fuse{!env_flag("GITCAP_NO_FFN_FUSE")};            // gitcap_dbg_config(7, .): ffn_txt.hip vs FC1 + split-K FC2 launches
 
 bool text_chain_ok(gitcap* h, int rows, int T) {
-    return g_chain_steps && T == 1 && !(h->want_hidden && h->cur_slot == 0) &&
+    return g_chain_steps && T == 1 && !(h->want_hidden && h->cur_slot == 0 && !h->pipelined) &&
            !(g_row_prologue && skinny_row_prologue_ok(rows, h->D, h->dec[0].qkvw.scale != nullptr));
 }
 
@@ -548,7 +551,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     const bool ffn_slices = ffn_txt_ok(D, c.dec_ffn) && c.dec_ffn / 64 <= h->nslab_max;
     const bool ffn_fused = ffn_slices && g_ffn_fuse && h->dec[0].fc1w.pk && h->dec[0].fc2w.pk;
     const int ks_f = ffn_slices ? c.dec_ffn / 64 : skinny_ksplit(c.dec_ffn);
-    const bool hid = h->want_hidden && h->cur_slot == 0 && t0 == 0;    // hidden-state export: a whole prefix, synchronous path
+    const bool hid = h->want_hidden && h->cur_slot == 0 && !h->pipelined && t0 == 0;    // hidden-state export: a whole prefix, synchronous path
     auto keep_txt = [&](int entry) -> hipError_t {                       // xs = the text rows' input of layer `entry`
         return hid ? hipMemcpyAsync(h->hid_txt + (size_t)entry * h->Mt * D, h->xs, (size_t)M * D * 4, hipMemcpyDeviceToDevice, s) : hipSuccess;
     };
@@ -652,34 +655,61 @@ int check_frames(gitcap* h, const void* frames, int B, int F, bool raw = false) 
     return 0;
 }
 
+int check_raw(gitcap* h, const uint8_t* frames, int B, int F, int H, int W) {
+    if (!frames || H <= 0 || W <= 0) return fail(h, GITCAP_ERR_ARG, "raw frames: null pointer or empty frames");
+    if ((int64_t)B * F * H * W * 3 > ((int64_t)1 << 40)) return fail(h, GITCAP_ERR_ARG, "raw frames: sizes overflow");
+    return check_frames(h, frames, B, F, true);
+}
+
 }  // namespace
 
 struct FrameSrc { const float* f32; const uint8_t* u8; int H, W; };     // fp32 NCHW (CLIP-normalised) or raw uint8 HWC BGR
 static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out, hipStream_t stream);
 
-// Pipelined submission: the image pass on the encoder stream, `text_loop` on the slot's decode stream (see gitcap_greedy_submit)
+// Pipelined submission: the image pass on the encoder stream, `text_loop` on the slot's decode stream (see gitcap_greedy_submit).
+// A failure after the first enqueue must not leave the slot unordered (the next user of the slot waits on ev_dec only): from
+// the moment anything may be on the slot's streams, every exit records ev_dec behind BOTH streams' work and marks the slot
+// used, and every exit restores slot 0 and the `pipelined` flag.
 template <typename TextLoop>
-static int submit_common(gitcap* h, const float* frames, int B, int F, float* visual_out, hipStream_t stream, int* ticket, TextLoop text_loop) {
+static int submit_common(gitcap* h, FrameSrc src, int B, int F, float* visual_out, hipStream_t stream, int* ticket, TextLoop text_loop) {
     const int slot = ticket_slot(h->next_ticket, gitcap::NSLOT);
     gitcap::Slot& sl = h->slots[slot];
     select_slot(h, slot);
+    bool enqueued = false;
+    auto leave = [&](int rc) {
+        h->pipelined = false;
+        if (rc && enqueued) {
+            // order the slot behind whatever was enqueued: s_txt waits for the encoder stream, ev_dec is recorded behind both
+            if (hipEventRecord(sl.ev_enc, h->s_enc) == hipSuccess) (void)hipStreamWaitEvent(sl.s_txt, sl.ev_enc, 0);
+            if (hipEventRecord(sl.ev_dec, sl.s_txt) == hipSuccess) sl.used = true;
+            else (void)hipDeviceSynchronize();          // no event to order on: drain instead
+            h->have_image = false;
+        }
+        select_slot(h, 0);
+        return rc;
+    };
+#define SUBMIT_OK(expr)                                                                                                \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) return leave(fail(h, GITCAP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_))); \
+    } while (0)
     // the image pass may start once the caller's stream has produced `frames` ...
-    HIP_OK(h, hipEventRecord(sl.ev_in, stream));
-    HIP_OK(h, hipStreamWaitEvent(h->s_enc, sl.ev_in, 0));
+    SUBMIT_OK(hipEventRecord(sl.ev_in, stream));
+    SUBMIT_OK(hipStreamWaitEvent(h->s_enc, sl.ev_in, 0));
     // ... and once the previous user of this slot's image K/V (four submissions ago) has finished decoding
-    if (sl.used) HIP_OK(h, hipStreamWaitEvent(h->s_enc, sl.ev_dec, 0));
+    if (sl.used) SUBMIT_OK(hipStreamWaitEvent(h->s_enc, sl.ev_dec, 0));
     h->pipelined = true;
-    int rc = encode_impl(h, FrameSrc{frames, nullptr, 0, 0}, B, F, visual_out, h->s_enc);
-    h->pipelined = false;
-    if (rc) { select_slot(h, 0); return rc; }
-    HIP_OK(h, hipEventRecord(sl.ev_enc, h->s_enc));
-    HIP_OK(h, hipStreamWaitEvent(sl.s_txt, sl.ev_enc, 0));
-    if ((rc = text_loop(sl.s_txt))) { select_slot(h, 0); return rc; }
-    HIP_OK(h, hipEventRecord(sl.ev_dec, sl.s_txt));
+    enqueued = true;
+    int rc = encode_impl(h, src, B, F, visual_out, h->s_enc);
+    if (rc) return leave(rc);
+    SUBMIT_OK(hipEventRecord(sl.ev_enc, h->s_enc));
+    SUBMIT_OK(hipStreamWaitEvent(sl.s_txt, sl.ev_enc, 0));
+    if ((rc = text_loop(sl.s_txt))) return leave(rc);
+    SUBMIT_OK(hipEventRecord(sl.ev_dec, sl.s_txt));
+#undef SUBMIT_OK
     sl.used = true;
     *ticket = h->next_ticket++;
-    select_slot(h, 0);
-    return 0;
+    return leave(0);
 }
 
 
@@ -1040,6 +1070,12 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
         }
     }
 
+    // gitcap_dbg_enc_tap (synchronous calls only): the residual stream entering block e
+    auto tap = [&](int e) -> hipError_t {
+        return (h->enc_tap && h->cur_slot == 0 && !h->pipelined && e < c.enc_layers)
+                   ? hipMemcpyAsync(h->enc_tap + (size_t)e * rows * Dv, h->x, (size_t)rows * Dv * 4, hipMemcpyDeviceToDevice, s) : hipSuccess;
+    };
+    HIP_OK(h, tap(0));
     // pre-LN blocks: x += proj(attn(LN1 x)); x += fc2(qgelu(fc1(LN2 x))).  Each residual GEMM also produces the
     // LayerNorm its consumer needs (LN2 of this block / LN1 of the next; the last one ln_post + temporal embedding); the first
     // LN1 came out of the ln_pre pass above.
@@ -1067,6 +1103,7 @@ static int encode_impl(gitcap* h, FrameSrc src, int B, int F, float* visual_out,
             const EncLayer& Nx = h->enc[i + 1];
             if ((rc = gemm_ln(h, s, false, fc2_in, c.enc_ffn, L.fc2w, L.fc2b, Mp, Dv, c.enc_ffn, h->x, h->x, Nx.ln1w, Nx.ln1b,
                               c.enc_ln_eps, rows, h->hb, nullptr, nullptr, 1, 1, nullptr, nullptr, f8))) return rc;
+            HIP_OK(h, tap(i + 1));
         } else {
             // the last block's FC2 is followed by ln_post (+ per-frame temporal embedding, model.py:380); frames of a clip are
             // already adjacent rows, so the concat along tokens (model.py:382) is the identity on this layout.  x itself is
@@ -1185,7 +1222,20 @@ int gitcap_greedy_submit(gitcap_t* h, const float* frames, int B, int F, int max
     POLL(h);
     int rc = greedy_check(h, max_len, stop, ids_out);
     if (rc) return rc;
-    return submit_common(h, frames, B, F, nullptr, (hipStream_t)stream, ticket, [&](hipStream_t s) {
+    return submit_common(h, FrameSrc{frames, nullptr, 0, 0}, B, F, nullptr, (hipStream_t)stream, ticket, [&](hipStream_t s) {
+        return greedy_text_loop(h, B, max_len, stop, ids_out, steps_out, s);
+    });
+}
+
+int gitcap_greedy_raw_submit(gitcap_t* h, const uint8_t* frames_hwc_bgr, int B, int F, int H, int W, int max_len, int stop,
+                             int64_t* ids_out, int32_t* steps_out, void* stream, int* ticket) {
+    if (!h || !ticket) return fail(h, GITCAP_ERR_ARG, "greedy_raw_submit: null argument");
+    GUARD(h);
+    POLL(h);
+    int rc = greedy_check(h, max_len, stop, ids_out);
+    if (rc) return rc;
+    if ((rc = check_raw(h, frames_hwc_bgr, B, F, H, W))) return rc;
+    return submit_common(h, FrameSrc{nullptr, frames_hwc_bgr, H, W}, B, F, nullptr, (hipStream_t)stream, ticket, [&](hipStream_t s) {
         return greedy_text_loop(h, B, max_len, stop, ids_out, steps_out, s);
     });
 }
@@ -1265,7 +1315,21 @@ int gitcap_beam_search_submit(gitcap_t* h, const float* frames, int B, int F, fl
     POLL(h);
     int rc = beam_check(h, beams, max_steps, per_node_beam_size, decoded_out, logprobs_out);
     if (rc) return rc;
-    return submit_common(h, frames, B, F, visual_out, (hipStream_t)stream, ticket, [&](hipStream_t s) {
+    return submit_common(h, FrameSrc{frames, nullptr, 0, 0}, B, F, visual_out, (hipStream_t)stream, ticket, [&](hipStream_t s) {
+        return beam_loop(h, B, beams, max_steps, length_penalty, per_node_beam_size, decoded_out, logprobs_out, step_logits_out, s);
+    });
+}
+
+int gitcap_beam_search_raw_submit(gitcap_t* h, const uint8_t* frames_hwc_bgr, int B, int F, int H, int W, float* visual_out, int beams,
+                                  int max_steps, float length_penalty, int per_node_beam_size, int64_t* decoded_out,
+                                  float* logprobs_out, float* step_logits_out, void* stream, int* ticket) {
+    if (!h || !ticket) return fail(h, GITCAP_ERR_ARG, "beam_search_raw_submit: null argument");
+    GUARD(h);
+    POLL(h);
+    int rc = beam_check(h, beams, max_steps, per_node_beam_size, decoded_out, logprobs_out);
+    if (rc) return rc;
+    if ((rc = check_raw(h, frames_hwc_bgr, B, F, H, W))) return rc;
+    return submit_common(h, FrameSrc{nullptr, frames_hwc_bgr, H, W}, B, F, visual_out, (hipStream_t)stream, ticket, [&](hipStream_t s) {
         return beam_loop(h, B, beams, max_steps, length_penalty, per_node_beam_size, decoded_out, logprobs_out, step_logits_out, s);
     });
 }
@@ -1438,6 +1502,12 @@ int gitcap_dbg_layernorm(const float* x, const float* gamma, const float* beta, 
                          float* out_f32, void* out_bf16, void* stream) {
     LnArgs a{x, D, gamma, beta, eps, rows, D, out_f32, D, (bf16_t*)out_bf16, D, nullptr, 1, 1, nullptr, nullptr, 0.f};
     return launch_layernorm(a, (hipStream_t)stream) == hipSuccess ? 0 : GITCAP_ERR_HIP;
+}
+
+int gitcap_dbg_enc_tap(gitcap_t* h, float* buf) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "dbg_enc_tap: null handle");
+    h->enc_tap = buf;
+    return 0;
 }
 
 int gitcap_hidden_states_enable(gitcap_t* h, int enable) {

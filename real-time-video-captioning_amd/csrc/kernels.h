@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include <atomic>
+#include <cstddef>
 
 // ---- big-tile bf16 MFMA GEMM:  C[m][n] = sum_k A[m][k] * W[n][k]  (+ epilogue) -------------
 enum GemmEpi {
@@ -48,6 +49,7 @@ struct GemmArgs {
                                   // (LAST: the residual + LayerNorm epilogue runs at the 256-VGPR limit and where the compiler spills
                                   // depends on the kernarg layout -- tests/test_isa_lint.py: test_gemm_ln_epilogue_keeps_its_spills_out_of_the_row_loops)
 };
+static_assert(offsetof(GemmArgs, f8_sat) + sizeof(unsigned long long*) == sizeof(GemmArgs), "f8_sat must stay the LAST field of GemmArgs (see its comment)");
 constexpr unsigned LN_SPIN_DEFAULT = 1u << 26;
 int device_cus();                 // compute units of the current device (cached per device; 256 when the query fails)
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);      // 128x128 tile (any M%128, N%128)

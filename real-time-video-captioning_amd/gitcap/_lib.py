@@ -36,6 +36,11 @@ SYMBOLS = {
     "gitcap_greedy_raw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gitcap_greedy_submit": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
     "gitcap_greedy_wait": (c_int, [c_void_p, c_int, c_void_p]),
+    "gitcap_greedy_raw_submit": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                         POINTER(c_int)]),
+    "gitcap_beam_search_raw_submit": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_int,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
+    "gitcap_dbg_enc_tap": (c_int, [c_void_p, c_void_p]),
     "gitcap_poll_errors": (c_int, [c_void_p]),
     "gitcap_preprocess": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gitcap_beam_topk": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

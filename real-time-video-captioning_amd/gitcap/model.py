@@ -36,15 +36,102 @@ class _Submission:
     """One gitcap_greedy_submit / gitcap_beam_search_submit (possibly several coalesced caller batches); keeps its buffers
     alive until every future attached to it has delivered its result (the frames are what a poisoned submission is re-run from)."""
 
-    def __init__(self, ticket, frames, outs, coalesced, users=1):
+    def __init__(self, ticket, frames, outs, coalesced, users=1, parts=None):
         self.ticket, self.frames, self.outs, self.coalesced, self.users = ticket, frames, outs, coalesced, users
+        self.parts = parts           # host-fed submissions: the callers' CPU tensors (frames is then their list; a re-run reads them)
         self.waited = False
+        self.done_ev = None          # recorded on the stream that waited: fires once the submission's last launch has finished
         self.poisoned = False        # in flight when the LayerNorm statistics exchange failed: results undefined, re-run
+        self.owner = None            # the model: forgets the submission once every future has delivered
+
+    def rows(self, r0, r1):
+        """Frames of caller rows [r0, r1) (what a re-run of a poisoned submission decodes again)."""
+        if self.parts is None:
+            return self.frames[r0:r1]
+        at = 0
+        for p in self.parts:
+            if at == r0 and at + p.shape[0] == r1:
+                return p
+            at += p.shape[0]
+        return torch.cat(list(self.parts), 0)[r0:r1]
 
     def release(self):
         self.users -= 1
         if self.users <= 0:
-            self.frames = None
+            self.frames = self.parts = None
+            if self.owner is not None:
+                self.owner._undelivered.discard(self)
+
+
+class _StagingRing:
+    """Host-fed submissions (the reference's callers hold CPU tensors: src/real_time_inference.py:39-58 OpenCV frames,
+    src/inference.py:45-51 a DataLoader batch): a ring of pinned host buffers + device buffers and ONE copy stream, so that the
+    host -> device copy of batch i + 1 runs under the compute of batch i.  The submission is made with the copy stream as its
+    `stream` argument (include/gitcap.h: gitcap_greedy_submit orders the image pass behind the work on that stream), so only the
+    image pass waits for the copy -- the caller's current stream never does.
+
+    Depth = the library's four slots.  An entry is reused four submissions later; before its device buffer is overwritten the
+    copy stream waits for the submission that read it (its `done_ev`, or the library's own wait while it is still in flight),
+    and the host waits for the entry's previous host -> device copy before touching the pinned buffer."""
+    DEPTH = 4
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.stream = torch.cuda.Stream(device=dev)
+        self.entries = [dict(pinned=None, device=None, ev=None, sub=None) for _ in range(self.DEPTH + 1)]   # [-1]: synchronous calls
+        self.n = 0
+
+    def stream_ptr(self):
+        return ctypes.c_void_p(self.stream.cuda_stream)
+
+    @staticmethod
+    def _grow(e, nbytes, dev):
+        if e["pinned"] is None or e["pinned"].numel() < nbytes:
+            cap = (nbytes + (1 << 20) - 1) >> 20 << 20
+            e["pinned"] = torch.empty((cap,), dtype=torch.uint8, pin_memory=True)
+            e["device"] = torch.empty((cap,), dtype=torch.uint8, device=dev)
+
+    def stage(self, model, parts, dtype, stream=None):
+        """Copy the CPU tensors `parts` (same trailing shape; concatenated along dim 0) to the device.  stream=None: the
+        pipelined form on the copy stream, next ring entry; else the synchronous form on that (the caller's) stream.
+        Returns (device tensor, entry)."""
+        sync = stream is not None
+        e = self.entries[-1] if sync else self.entries[self.n % self.DEPTH]
+        if not sync:
+            self.n += 1
+        st = stream if sync else self.stream
+        rows = sum(p.shape[0] for p in parts)
+        shape = (rows,) + tuple(parts[0].shape[1:])
+        nbytes = rows * int(np.prod(parts[0].shape[1:])) * torch.empty((), dtype=dtype).element_size()
+        if e["ev"] is not None:
+            e["ev"].synchronize()                     # the pinned buffer's previous host -> device copy
+        prev = e["sub"]
+        if prev is not None:                          # the device buffer's previous reader (an image pass)
+            if prev.done_ev is not None:
+                st.wait_event(prev.done_ev)
+            elif not prev.poisoned and prev in model._inflight:
+                try:
+                    model._call("gitcap_greedy_wait", prev.ticket, ctypes.c_void_p(st.cuda_stream))
+                except _lib.GitcapExchangeTimeout:    # (the device was drained when the failure was taken)
+                    prev.poisoned = True
+            e["sub"] = None
+        self._grow(e, nbytes, self.dev)
+        dview = e["device"][:nbytes].view(dtype).view(shape)
+        direct = len(parts) == 1 and parts[0].is_pinned() and parts[0].dtype == dtype and parts[0].is_contiguous()
+        if direct:
+            hsrc = parts[0]                           # already page-locked (DataLoader(pin_memory=True), a capture ring): no staging copy
+        else:
+            hsrc = e["pinned"][:nbytes].view(dtype).view(shape)
+            r0 = 0
+            for p in parts:
+                hsrc[r0:r0 + p.shape[0]].copy_(p)     # (ATen's parallel CPU copy; converts the dtype if it has to)
+                r0 += p.shape[0]
+        with torch.cuda.stream(st):
+            dview.copy_(hsrc, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        e["ev"] = ev
+        return dview, e
 
 
 class _Future:
@@ -102,7 +189,7 @@ class CaptionFuture(_Future):
             return ids.to(self._out_device) if self._out_device != ids.device else ids
 
         def rerun():
-            ids = m._greedy_decode(sub.frames[self._r0:self._r1], self._max_len, self._mode)
+            ids = m._greedy_decode(sub.rows(self._r0, self._r1), self._max_len, self._mode)
             return ids.to(self._out_device) if self._out_device != ids.device else ids
 
         synced = self._mode == STOP_ALL_SEP or self._out_device.type == "cpu"
@@ -130,7 +217,8 @@ class InferFuture(_Future):
                     "logits_dict": [] if steps is None else steps, "visual_features": mv(vis)}
 
         def rerun():
-            r = m._infer_device(sub.frames, sync=True, save_logits=self._save, want_visual=sub.outs[3] is not None, **self._kw)
+            r = m._infer_device(m._to_device(sub.rows(0, sub.outs[0].shape[0])), sync=True, save_logits=self._save,
+                                want_visual=sub.outs[3] is not None, **self._kw)
             sub.outs = r
             return extract()
 
@@ -185,6 +273,8 @@ class GitCaptioner(nn.Module):
         self._last_memory = None
         self._pending, self._pending_key = [], None
         self._inflight = []                             # submissions whose wait has not been enqueued yet (<= 4)
+        self._undelivered = set()                       # waited for, but a future has still to hand out (or re-run) its rows
+        self._ring = None                               # _StagingRing, made when the first CPU tensor arrives
         self._lib = _lib.load()                         # raises if libgitcap.so is missing
         self._create()
         if weights is not None:
@@ -228,7 +318,16 @@ class GitCaptioner(nn.Module):
 
     def _call(self, name, *args):
         rc = getattr(self._lib, name)(self._handle, *args)
+        if rc == _lib.ERR_EXCHANGE:
+            # whichever call learns of a failed statistics exchange: every submission whose rows have not been handed out yet
+            # (in flight, or already stream-waited by a synchronous call but not delivered) holds undefined ids
+            self._poison_inflight()
         _lib.check(self._lib, self._handle, rc, name)
+
+    def _staging(self):
+        if self._ring is None:
+            self._ring = _StagingRing(self._dev)
+        return self._ring
 
     def _submit(self, name, *args):
         """A gitcap_*_submit call.  If the library reports a failed statistics exchange at this entry (GITCAP_ERR_EXCHANGE, once)
@@ -268,15 +367,22 @@ class GitCaptioner(nn.Module):
             try:
                 with torch.cuda.device(self._dev):
                     self._call("gitcap_greedy_wait", sub.ticket, self._stream())
+                    sub.done_ev = torch.cuda.Event()
+                    sub.done_ev.record(torch.cuda.current_stream(self._dev))
                 sub.waited = True
             except _lib.GitcapExchangeTimeout:   # raised now, or this ticket was in flight when it was raised: everything
                 self._poison_inflight()          # submitted so far is undefined (the C ABI marks the same tickets)
                 sub.poisoned = True
         if sub in self._inflight:
             self._inflight.remove(sub)
+            if sub.users > 0:                    # until every future has delivered, a failure reported later still marks it
+                sub.owner = self
+                self._undelivered.add(sub)
 
     def _poison_inflight(self):
         for sub in self._inflight:
+            sub.poisoned = True
+        for sub in self._undelivered:            # stream-waited (e.g. by a synchronous call's _drain) but not handed out yet
             sub.poisoned = True
 
     def _drain(self):
@@ -343,33 +449,54 @@ class GitCaptioner(nn.Module):
         return _rebuild, (self.cfg.to_dict(), self._weights, kw)
 
     # ------------------------------------------------------------------ helpers
-    def _frames(self, x: torch.Tensor) -> torch.Tensor:
-        if x.dim() == 4:                                  # [B,3,H,W] single image -> one frame
-            x = x.unsqueeze(1)
-        if x.dim() != 5 or x.shape[2] != 3 or x.shape[3] != self.cfg.image_size or x.shape[4] != self.cfg.image_size:
-            raise ValueError(f"expected frames [B,F,3,{self.cfg.image_size},{self.cfg.image_size}], got {tuple(x.shape)}")
+    def _check_frames(self, x: torch.Tensor):
+        """Shape checks only (nothing is moved): -> (5-D view, raw) with raw = uint8 BGR camera frames [B,F,H,W,3] (OpenCV layout,
+        real_time_inference.py:39; [F,H,W,3] = one clip) as opposed to transformed frames [B,F,3,S,S] ([B,3,S,S] = one frame each)."""
+        raw = x.dtype == torch.uint8
+        if raw:
+            if x.dim() == 4:
+                x = x.unsqueeze(0)
+            if x.dim() != 5 or x.shape[-1] != 3:
+                raise ValueError(f"expected uint8 frames [B,F,H,W,3], got {tuple(x.shape)}")
+            if min(x.shape[2], x.shape[3]) < 1:
+                raise ValueError("empty frames")
+        else:
+            if x.dim() == 4:                                  # [B,3,H,W] single image -> one frame
+                x = x.unsqueeze(1)
+            if x.dim() != 5 or x.shape[2] != 3 or x.shape[3] != self.cfg.image_size or x.shape[4] != self.cfg.image_size:
+                raise ValueError(f"expected frames [B,F,3,{self.cfg.image_size},{self.cfg.image_size}], got {tuple(x.shape)}")
         if x.shape[0] == 0:
             raise ValueError("empty batch")
         if x.shape[1] > self.max_frames:
             raise ValueError(f"{x.shape[1]} frames per clip > max_frames={self.max_frames}")
-        x = x.to(device=self._dev, dtype=torch.float32).contiguous()
+        return x, raw
+
+    def _to_device(self, x: torch.Tensor) -> torch.Tensor:
+        """Checked frames -> contiguous, 16-byte aligned device tensor (fp32 NCHW or uint8 HWC) for a SYNCHRONOUS call.  A CPU
+        tensor (real_time_inference.py:57) goes through the pinned staging entry of the synchronous calls on the current stream
+        (a pageable x.to(device) is a blocking, runtime-staged copy)."""
+        dtype = torch.uint8 if x.dtype == torch.uint8 else torch.float32
+        if x.device.type == "cpu":
+            with torch.cuda.device(self._dev):
+                dv, _ = self._staging().stage(self, [x], dtype, stream=torch.cuda.current_stream(self._dev))
+            return dv
+        x = x.to(device=self._dev, dtype=dtype).contiguous()
         if x.data_ptr() % 16:
             x = x.clone()
         return x
 
+    def _frames(self, x: torch.Tensor) -> torch.Tensor:
+        x, raw = self._check_frames(x)
+        if raw:
+            raise ValueError("this call takes transformed fp32 frames [B,F,3,S,S], not uint8 camera frames")
+        return self._to_device(x)
+
     def _raw_frames(self, x: torch.Tensor) -> torch.Tensor:
         """uint8 BGR camera frames [B,F,H,W,3] (OpenCV layout, real_time_inference.py:39) or [F,H,W,3] for one clip."""
-        if x.dim() == 4:
-            x = x.unsqueeze(0)
-        if x.dim() != 5 or x.shape[-1] != 3:
-            raise ValueError(f"expected uint8 frames [B,F,H,W,3], got {tuple(x.shape)}")
-        if x.shape[0] == 0:
-            raise ValueError("empty batch")
-        if x.shape[1] > self.max_frames:
-            raise ValueError(f"{x.shape[1]} frames per clip > max_frames={self.max_frames}")
-        if min(x.shape[2], x.shape[3]) < 1:
-            raise ValueError("empty frames")
-        return x.to(device=self._dev).contiguous()
+        x, raw = self._check_frames(x)
+        if not raw:
+            raise ValueError(f"expected uint8 frames [B,F,H,W,3], got {x.dtype}")
+        return self._to_device(x)
 
     def _ids(self, y: torch.Tensor) -> torch.Tensor:
         return y.to(device=self._dev, dtype=torch.int64).contiguous()
@@ -442,22 +569,10 @@ class GitCaptioner(nn.Module):
         Without a tokenizer ``cap`` is None and n counts the tokens before SEP."""
         if on_device is None:
             on_device = beam_size * 2 <= 16
-        fr = self._frames(x)
-        chunks = []
-        if on_device:
-            futs = [self.infer_async(fr[b0:b0 + self.max_batch], beam_size=beam_size, max_steps=max_steps, save_logits=True,
-                                     visual_features=True) for b0 in range(0, fr.shape[0], self.max_batch)]
-            for f in futs:
-                r = f.result()
-                chunks.append((r["predictions"], r["logprobs"], r["logits_dict"], r["visual_features"]))
-        else:
-            for b0 in range(0, fr.shape[0], self.max_batch):
-                r = self.infer(fr[b0:b0 + self.max_batch], beam_size=beam_size, max_steps=max_steps, save_logits=True, on_device=False)
-                steps = torch.from_numpy(np.stack([np.asarray(st) for st in r["logits_dict"]])).to(self._dev)
-                chunks.append((r["predictions"], r["logprobs"], steps, r["visual_features"]))
+        fr, _ = self._check_frames(x)             # a CPU tensor stays where it is: every chunk is staged as it is submitted
         out = []
-        for pred, logprobs, steps, vis in chunks:                                # steps: [S, Bc * beams, V] on the device
-            pred_h = pred.cpu()
+
+        def finish(pred, pred_h, logprobs, steps, vis):       # per-clip bookkeeping of one chunk; steps: [S, Bc * beams, V] on the device
             for b in range(pred.shape[0]):
                 dist_all = steps[:, b * beam_size:(b + 1) * beam_size]              # [S, beams, V]
                 ids = pred_h[b].tolist()
@@ -477,6 +592,35 @@ class GitCaptioner(nn.Module):
                 out.append({"predictions": pred[b:b + 1], "logprobs": logprobs[b:b + 1],
                             "logits_dict": [a for a in dist_all.cpu().numpy()],
                             "visual_features": vis[b:b + 1], "output": output, "cap": cap})
+
+        if on_device:
+            # a sliding window of submissions, each consumed (and its [max_steps - 1, B * beams, V] logits tensor dropped) before
+            # the next is made: device memory is bounded by the window, not by the number of chunks
+            kw = dict(beam_size=beam_size, max_steps=max_steps, save_logits=True, visual_features=True)
+            futs = []
+
+            def take(f, b0):
+                r = f.result()
+                pred_h = r["predictions"].cpu()           # a host synchronisation: the result can be vouched for now
+                try:
+                    self.poll_errors()
+                except _lib.GitcapExchangeTimeout:        # (the failure poisoned what is in flight; this chunk is re-run here)
+                    r = self.infer_async(fr[b0:b0 + self.max_batch], **kw).result()
+                    pred_h = r["predictions"].cpu()
+                    self.poll_errors()
+                finish(r["predictions"], pred_h, r["logprobs"], r["logits_dict"], r["visual_features"])
+
+            for b0 in range(0, fr.shape[0], self.max_batch):
+                if len(futs) >= 3:
+                    take(*futs.pop(0))
+                futs.append((self.infer_async(fr[b0:b0 + self.max_batch], **kw), b0))
+            while futs:
+                take(*futs.pop(0))
+        else:
+            for b0 in range(0, fr.shape[0], self.max_batch):
+                r = self.infer(fr[b0:b0 + self.max_batch], beam_size=beam_size, max_steps=max_steps, save_logits=True, on_device=False)
+                steps = torch.from_numpy(np.stack([np.asarray(st) for st in r["logits_dict"]])).to(self._dev)
+                finish(r["predictions"], r["predictions"].cpu(), r["logprobs"], steps, r["visual_features"])
         return out
 
     @torch.no_grad()
@@ -520,13 +664,12 @@ class GitCaptioner(nn.Module):
 
     def _greedy_decode(self, src, max_len, mode):
         self._drain()
-        raw = src.dtype == torch.uint8            # camera frames [B,F,H,W,3] uint8 BGR: transform fused into the patch gather
-        fr = self._raw_frames(src) if raw else self._frames(src)
+        fr, raw = self._check_frames(src)         # raw: camera frames [B,F,H,W,3] uint8 BGR, transform fused into the patch gather
         B, F = fr.shape[:2]
         outs, steps_all = [], []
         with torch.cuda.device(self._dev):
             for b0 in range(0, B, self.max_batch):
-                chunk = fr[b0:b0 + self.max_batch]
+                chunk = self._to_device(fr[b0:b0 + self.max_batch])      # (a CPU tensor: staged chunk by chunk, stream ordered)
                 ids = torch.empty((chunk.shape[0], max_len + 1), dtype=torch.int64, device=self._dev)
                 steps = torch.zeros((1,), dtype=torch.int32, device=self._dev)
                 if raw:
@@ -560,6 +703,12 @@ class GitCaptioner(nn.Module):
         loops (latency bound) of the batches before it on the handle's internal HIP streams.  Call
         ``.result()`` (in submission order) to make the current stream wait and get the ids.
 
+        `src` may be transformed fp32 frames [B,F,3,S,S] or uint8 BGR camera frames [B,F,H,W,3] (the transform of
+        dataloader.py:18-32 then runs on the device, fused with the patch gather), on the device or -- what the reference's
+        callers hold -- in HOST memory: a CPU tensor goes through a pinned staging ring and a copy stream, so its
+        host -> device copy runs under the compute of the batches before it (page-locked tensors, e.g. from
+        DataLoader(pin_memory=True), are copied from where they are).  A CPU tensor must not be modified before ``result()``.
+
         ``coalesce=k`` (dynamic batching): k consecutive calls with the same shape are concatenated and
         run as ONE pass of k*B clips (the per-clip results are bitwise the same: the kernels are batch
         invariant); a ``result()`` on a batch that is still waiting for partners flushes it.  Needs
@@ -568,12 +717,15 @@ class GitCaptioner(nn.Module):
         mode = {"all_sep": STOP_ALL_SEP, "never": STOP_NEVER}[stop]
         if max_len > self.max_text_len:
             raise ValueError(f"max_len {max_len} > max_text_len={self.max_text_len} the handle was created for")
-        fr = self._frames(src)
+        fr, raw = self._check_frames(src)         # nothing is copied yet: a CPU batch is staged when its group is submitted
         B = fr.shape[0]
         if B * max(1, coalesce) > self.max_batch:
             raise ValueError(f"batch {B} x coalesce {coalesce} > max_batch={self.max_batch}")
+        host = fr.device.type == "cpu"
+        if not host:
+            fr = self._to_device(fr)
         fut = CaptionFuture(self, fr, mode, max_len, src.device)
-        key = (tuple(fr.shape), max_len, mode)
+        key = (tuple(fr.shape), max_len, mode, raw, host)
         if self._pending and self._pending_key != key:
             self._flush_pending()
         self._pending.append(fut)
@@ -582,26 +734,46 @@ class GitCaptioner(nn.Module):
             self._flush_pending()
         return fut
 
+    def _stage_group(self, parts, raw):
+        """Host-fed submission: the callers' CPU tensors -> one ring entry (pinned staging unless the single tensor is already
+        page-locked) -> device, on the copy stream.  Returns (device frames, ring entry, stream the submission is ordered behind)."""
+        ring = self._staging()
+        dv, entry = ring.stage(self, parts, torch.uint8 if raw else torch.float32)
+        return dv, entry, ring.stream_ptr()
+
     def _flush_pending(self):
         """Submit the waiting batches as one pass and hand each future its row range."""
         group, self._pending = self._pending, []
         if not group:
             return
-        frames = group[0]._frames if len(group) == 1 else torch.cat([f._frames for f in group], 0)
-        B, F = frames.shape[:2]
+        raw, host = self._pending_key[3], self._pending_key[4]
         max_len, mode = group[0]._max_len, group[0]._mode
         while len(self._inflight) >= 4:        # four slots: the oldest submission's slot is about to be reused
             self._wait_submission(self._inflight[0])
         with torch.cuda.device(self._dev):
+            parts = entry = None
+            if host:
+                parts = [f._frames for f in group]
+                frames, entry, stream = self._stage_group(parts, raw)
+            else:
+                frames = group[0]._frames if len(group) == 1 else torch.cat([f._frames for f in group], 0)
+                stream = self._stream()
+            B, F = frames.shape[:2]
             ids = torch.empty((B, max_len + 1), dtype=torch.int64, device=self._dev)
             steps = torch.zeros((1,), dtype=torch.int32, device=self._dev)
             ticket = ctypes.c_int(-1)
-            self._submit("gitcap_greedy_submit", ctypes.c_void_p(frames.data_ptr()), B, F, max_len,
-                       STOP_NEVER if len(group) > 1 else mode,       # the stop rule is per caller batch: applied in result()
-                       ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(steps.data_ptr()), self._stream(),
-                       ctypes.byref(ticket))
+            stop = STOP_NEVER if len(group) > 1 else mode       # the stop rule is per caller batch: applied in result()
+            if raw:
+                self._submit("gitcap_greedy_raw_submit", ctypes.c_void_p(frames.data_ptr()), B, F, frames.shape[2], frames.shape[3],
+                             max_len, stop, ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(steps.data_ptr()), stream,
+                             ctypes.byref(ticket))
+            else:
+                self._submit("gitcap_greedy_submit", ctypes.c_void_p(frames.data_ptr()), B, F, max_len, stop,
+                             ctypes.c_void_p(ids.data_ptr()), ctypes.c_void_p(steps.data_ptr()), stream, ctypes.byref(ticket))
         self._last_memory = None
-        shared = _Submission(ticket.value, frames, (ids, steps), len(group) > 1, users=len(group))
+        shared = _Submission(ticket.value, frames, (ids, steps), len(group) > 1, users=len(group), parts=parts)
+        if entry is not None:
+            entry["sub"] = shared
         self._inflight.append(shared)
         r0 = 0
         for f in group:
@@ -629,7 +801,9 @@ class GitCaptioner(nn.Module):
         """GIT inference with beam search = ``GenerativeImageTextModel.infer`` (model.py:426-462) driven by
         ``GeneratorWithBeamSearchV2.search`` (model.py:479-678; defaults of :702-708).  Returns the
         reference's output dict: predictions [B, max_steps] (CLS-prefixed, EOS padded), logprobs [B,1],
-        logits_dict (per-step [B*beams, V] host arrays when save_logits, cf. :521) and visual_features.
+        logits_dict (when save_logits, cf. :521: per-step [B*beams, V] host arrays from the host operator, which stops once every
+        clip is done (:640); ONE device tensor [max_steps - 1, B*beams, V] from the device search, which runs every step) and
+        visual_features.
         Default: the device-resident search (no host sync per step); on_device=False runs the host-side
         operator of gitcap/search.py (needed for num_keep_best > 1 or save_logits)."""
         from .search import GeneratorWithBeamSearch
@@ -638,10 +812,11 @@ class GitCaptioner(nn.Module):
         if max_steps > self.max_text_len:
             raise ValueError(f"max_steps {max_steps} > max_text_len={self.max_text_len}")
         self._drain()
-        fr = self._frames(src)
+        fr, raw = self._check_frames(src)
         B, F = fr.shape[:2]
         if B > self.max_batch:
             raise ValueError(f"batch {B} > max_batch={self.max_batch}")
+        fr = self._to_device(fr)
         if on_device is None:
             on_device = (num_keep_best == 1 and not save_logits and beam_size * per_node_beam_size <= 16
                          and per_node_beam_size >= 2)
@@ -649,7 +824,7 @@ class GitCaptioner(nn.Module):
             self._check_device_search(beam_size, per_node_beam_size, num_keep_best)
             decoded, logprobs, steps, vis = self._infer_device(fr, beam_size=beam_size, max_steps=max_steps, length_penalty=length_penalty,
                                                                per_node_beam_size=per_node_beam_size, sync=True,
-                                                               save_logits=save_logits, want_visual=False)
+                                                               save_logits=save_logits, want_visual=False, raw=raw)
             return {"predictions": decoded, "logprobs": logprobs[:, None], "logits_dict": [] if steps is None else steps,
                     "visual_features": None}
         _, vis = self.forward_image_enc(fr)
@@ -676,16 +851,20 @@ class GitCaptioner(nn.Module):
         if beam_size * per_node_beam_size > 16:
             raise ValueError("the device-resident search ranks at most 16 candidates per clip")
 
-    def _infer_device(self, fr, *, beam_size, max_steps, length_penalty, per_node_beam_size, sync, save_logits, want_visual):
-        """The device-resident search on frames already staged: synchronously on the current stream (sync=True; per-step logits
-        are not available there) or as a pipelined submission.  Returns (decoded, logprobs, step logits | None, visual | None)
-        [+ the ticket when submitted]."""
+    def _infer_device(self, fr, *, beam_size, max_steps, length_penalty, per_node_beam_size, sync, save_logits, want_visual,
+                      raw=None, stream=None):
+        """The device-resident search on frames already on the device (fp32 NCHW, or raw uint8 HWC): synchronously on the current
+        stream (sync=True; per-step logits are not available there) or as a pipelined submission ordered behind `stream` (default:
+        the current stream; a host-fed submission passes the copy stream).  Returns (decoded, logprobs, step logits | None,
+        visual | None) [+ the ticket when submitted]."""
+        if raw is None:
+            raw = fr.dtype == torch.uint8
         B, F = fr.shape[:2]
         decoded = torch.empty((B, max_steps), dtype=torch.int64, device=self._dev)
         logprobs = torch.empty((B,), dtype=torch.float32, device=self._dev)
         null = ctypes.c_void_p(None)
         with torch.cuda.device(self._dev):
-            if sync and not save_logits and not want_visual:
+            if sync and not save_logits and not want_visual and not raw:
                 self._drain()
                 self._call("gitcap_beam_search", ctypes.c_void_p(fr.data_ptr()), B, F, beam_size, max_steps,
                            ctypes.c_float(length_penalty), per_node_beam_size, ctypes.c_void_p(decoded.data_ptr()),
@@ -697,12 +876,16 @@ class GitCaptioner(nn.Module):
             while len(self._inflight) >= 4:
                 self._wait_submission(self._inflight[0])
             ticket = ctypes.c_int(-1)
-            self._submit("gitcap_beam_search_submit", ctypes.c_void_p(fr.data_ptr()), B, F,
-                       ctypes.c_void_p(vis.data_ptr()) if want_visual else null, beam_size, max_steps, ctypes.c_float(length_penalty),
-                       per_node_beam_size, ctypes.c_void_p(decoded.data_ptr()), ctypes.c_void_p(logprobs.data_ptr()),
-                       ctypes.c_void_p(steps.data_ptr()) if save_logits else null, self._stream(), ctypes.byref(ticket))
+            tail = (ctypes.c_void_p(vis.data_ptr()) if want_visual else null, beam_size, max_steps, ctypes.c_float(length_penalty),
+                    per_node_beam_size, ctypes.c_void_p(decoded.data_ptr()), ctypes.c_void_p(logprobs.data_ptr()),
+                    ctypes.c_void_p(steps.data_ptr()) if save_logits else null, stream if stream is not None else self._stream(),
+                    ctypes.byref(ticket))
+            if raw:
+                self._submit("gitcap_beam_search_raw_submit", ctypes.c_void_p(fr.data_ptr()), B, F, fr.shape[2], fr.shape[3], *tail)
+            else:
+                self._submit("gitcap_beam_search_submit", ctypes.c_void_p(fr.data_ptr()), B, F, *tail)
             self._last_memory = None
-            if sync:                           # (a re-run, or a synchronous call that wants logits / visual features)
+            if sync:                           # (a re-run, or a synchronous call that wants logits / visual features / takes raw frames)
                 self._call("gitcap_beam_search_wait", ticket.value, self._stream())
                 return decoded, logprobs, steps, vis
         return decoded, logprobs, steps, vis, ticket.value
@@ -714,7 +897,8 @@ class GitCaptioner(nn.Module):
         submissions (of this kind or of greedy_decode_async) may be in flight, so one batch's image pass overlaps the search loops
         of the batches before it.  ``result()`` returns ``infer``'s dict; with ``save_logits`` its ``logits_dict`` is one device
         tensor [max_steps - 1, B * beam_size, V] (the raw logits of every step, model.py:521), with ``visual_features`` the fp32
-        features [B, F*N, Dv] (model.py:460).  Results are bitwise those of the synchronous call."""
+        features [B, F*N, Dv] (model.py:460).  Results are bitwise those of the synchronous call.  `src` as in
+        greedy_decode_async: fp32 frames or uint8 camera frames, on the device or in host memory (staged through the pinned ring)."""
         self._check_device_search(beam_size, per_node_beam_size, 1)
         if beam_size > self.max_beams:
             raise ValueError(f"beam_size {beam_size} > max_beams={self.max_beams} the handle was created for")
@@ -722,12 +906,24 @@ class GitCaptioner(nn.Module):
             raise ValueError(f"max_steps {max_steps} > max_text_len={self.max_text_len}")
         if self._pending:
             self._flush_pending()
-        fr = self._frames(src)
+        fr, raw = self._check_frames(src)
         if fr.shape[0] > self.max_batch:
             raise ValueError(f"batch {fr.shape[0]} > max_batch={self.max_batch}")
         kw = dict(beam_size=beam_size, max_steps=max_steps, length_penalty=length_penalty, per_node_beam_size=per_node_beam_size)
-        decoded, logprobs, steps, vis, ticket = self._infer_device(fr, sync=False, save_logits=save_logits, want_visual=visual_features, **kw)
-        sub = _Submission(ticket, fr, (decoded, logprobs, steps, vis), False)
+        parts = entry = stream = None
+        if fr.device.type == "cpu":
+            while len(self._inflight) >= 4:      # (before the staging: the entry about to be reused belongs to the oldest)
+                self._wait_submission(self._inflight[0])
+            parts = [fr]
+            with torch.cuda.device(self._dev):
+                fr, entry, stream = self._stage_group(parts, raw)
+        else:
+            fr = self._to_device(fr)
+        decoded, logprobs, steps, vis, ticket = self._infer_device(fr, sync=False, save_logits=save_logits, want_visual=visual_features,
+                                                                   raw=raw, stream=stream, **kw)
+        sub = _Submission(ticket, fr, (decoded, logprobs, steps, vis), False, parts=parts)
+        if entry is not None:
+            entry["sub"] = sub
         self._inflight.append(sub)
         return InferFuture(self, sub, kw, src.device, save_logits)
 
