@@ -235,6 +235,13 @@ int gitcap_beam_search_raw_submit(gitcap_t* h, const uint8_t* frames_hwc_bgr, in
                                   int beams, int max_steps, float length_penalty, int per_node_beam_size,
                                   int64_t* decoded_out, float* logprobs_out, float* step_logits_out, void* stream, int* ticket);
 
+/* Host-side staging copy for host-fed callers (no reference counterpart): bytes from pageable memory (a DataLoader batch without
+ * pin_memory, OpenCV frames) into a page-locked staging buffer, split over up to 8 threads -- as many as the process may really use
+ * (affinity mask, cgroup CPU quota; GITCAP_HOST_COPY_THREADS overrides).  Plain memcpy semantics, blocking, no device work.
+ * (A framework's own parallel copy may size its pool to the whole machine: under a CPU quota that costs tens of milliseconds per
+ * 58 MB batch, measured; this is the copy gitcap/model.py: _StagingRing uses.) */
+int gitcap_host_copy(void* dst, const void* src, int64_t bytes);
+
 /* Health of the in-kernel statistics exchange (no reference counterpart).  The residual GEMMs that normalise their own output
  * rows exchange LayerNorm statistics between the workgroups of a row block (co-residency).  If a workgroup ever
  * gives up waiting (about 30 s: its siblings cannot become resident because another process or a CU-masked stream holds the
@@ -294,7 +301,8 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
  * FC1 -> GELU -> FC2 as one launch over hidden slices on/off; 8: fragment-major copies of the text-path weights at the next
  * gitcap_finalize_weights on/off; 9: 8-wave workgroups for text-attention launches of more (row, head) units than CUs on/off;
  * 10: the vocabulary head's four-tile workgroups that share the activation rows through LDS on/off; 11: three-wave workgroups
- * that share the slab reduce of the one/two-row prologue on/off.  Returns the previous value (< 0: bad key).  The switches are process-wide atomics: a call on another thread sees either value,
+ * that share the slab reduce of the one/two-row prologue on/off; 12: the 256x256 GEMM's K loop with four barriers per K-tile instead of
+ * eight on/off.  Returns the previous value (< 0: bad key).  The switches are process-wide atomics: a call on another thread sees either value,
  * and either value gives the same bits. */
 int gitcap_dbg_config(int key, int value);
 /* attn_full: qkv [G*S][3*H*64] bf16 -> ctx [G*S][H*64] bf16 */

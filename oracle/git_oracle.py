@@ -124,36 +124,56 @@ class GitOracle:
         return x.transpose(1, 2).reshape(B, T, H * d)
 
     # ------------------------------------------------------------------ encoder (a2,a3)
-    def encode_frames(self, frames: torch.Tensor) -> torch.Tensor:
-        """frames [B,F,3,H,W] fp32 NCHW -> visual features [B, F*N, Dv]
-        (= ln_post output + temporal embedding, frames concatenated along tokens:
-        model.py:378-382)."""
+    def embed_frames(self, frames: torch.Tensor) -> torch.Tensor:
+        """frames [B,F,3,H,W] -> the ViT's residual stream after ln_pre, [B*F, N, Dv] (patchify conv k = stride = p without bias,
+        CLS, position embedding, ln_pre: modeling_git.py:343-423, :591-610)."""
         cfg = self.cfg
         B, F = frames.shape[:2]
-        p, g, Dv, H = cfg.patch_size, cfg.grid, cfg.enc_width, cfg.enc_heads
+        p, g, Dv = cfg.patch_size, cfg.grid, cfg.enc_width
         x = frames.reshape(B * F, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(B * F, g * g, 3 * p * p)
         x = torch.matmul(_r(x.float(), self.bf), self.w["enc.patch_w"].t())        # conv k=stride=p, no bias
         cls = self.w["enc.cls"].expand(B * F, 1, Dv)
         x = torch.cat([cls, x], dim=1) + self.w["enc.pos"][None]
-        x = self._ln(x, "enc.ln_pre", cfg.enc_ln_eps)
+        return self._ln(x, "enc.ln_pre", cfg.enc_ln_eps)
+
+    def enc_block(self, i: int, x: torch.Tensor) -> torch.Tensor:
+        """One pre-LN CLIP-ViT block (modeling_git.py:465-553) on the residual stream x [nf, N, Dv]."""
+        cfg = self.cfg
+        Dv, H = cfg.enc_width, cfg.enc_heads
         N = x.shape[1]
         full = torch.full((N,), N)
-        for i in range(cfg.enc_layers):
-            pre = f"enc.L{i}."
-            h = self._ln(x, pre + "ln1", cfg.enc_ln_eps)
-            qkv = _r(self._lin(h, pre + "qkv", True), self.bf)
-            q, k, v = (self._heads(t, H) for t in qkv.split(Dv, dim=-1))
-            a = self._merge(self._attn(q, k, v, full))
-            x = x + self._lin(a, pre + "proj", True)
-            h = self._ln(x, pre + "ln2", cfg.enc_ln_eps)
-            h = self._lin(h, pre + "fc1", True)
-            h = h * torch.sigmoid(1.702 * h)                                       # QuickGELU
-            x = x + self._lin(h, pre + "fc2", True)
+        pre = f"enc.L{i}."
+        h = self._ln(x, pre + "ln1", cfg.enc_ln_eps)
+        qkv = _r(self._lin(h, pre + "qkv", True), self.bf)
+        q, k, v = (self._heads(t, H) for t in qkv.split(Dv, dim=-1))
+        a = self._merge(self._attn(q, k, v, full))
+        x = x + self._lin(a, pre + "proj", True)
+        h = self._ln(x, pre + "ln2", cfg.enc_ln_eps)
+        h = self._lin(h, pre + "fc1", True)
+        h = h * torch.sigmoid(1.702 * h)                                       # QuickGELU
+        return x + self._lin(h, pre + "fc2", True)
+
+    def enc_post(self, x: torch.Tensor, B: int, F: int) -> torch.Tensor:
+        """ln_post + temporal embedding + concat along tokens (model.py:379-382): [B*F, N, Dv] -> [B, F*N, Dv]."""
+        cfg = self.cfg
+        N, Dv = x.shape[1], cfg.enc_width
         x = self._ln(x, "enc.ln_post", cfg.enc_ln_eps)
         x = x.view(B, F, N, Dv)
         if cfg.num_frames:
             x = x + self.w["temporal"][:F][None, :, None, :]
         return x.reshape(B, F * N, Dv)
+
+    def encode_frames(self, frames: torch.Tensor, taps: Optional[list] = None) -> torch.Tensor:
+        """frames [B,F,3,H,W] fp32 NCHW -> visual features [B, F*N, Dv]
+        (= ln_post output + temporal embedding, frames concatenated along tokens:
+        model.py:378-382).  taps (a list, optional): receives the residual stream entering every block."""
+        B, F = frames.shape[:2]
+        x = self.embed_frames(frames)
+        for i in range(self.cfg.enc_layers):
+            if taps is not None:
+                taps.append(x)
+            x = self.enc_block(i, x)
+        return self.enc_post(x, B, F)
 
     # ------------------------------------------------------------------ projection (a4)
     def project(self, visual: torch.Tensor) -> torch.Tensor:
@@ -183,6 +203,19 @@ class GitOracle:
         D, H = cfg.dec_width, cfg.dec_heads
         qkv = _r(self._lin(x, f"dec.L{i}.qkv", img), self.bf)
         return self._heads(qkv[..., D:2 * D], H), self._heads(qkv[..., 2 * D:], H)
+
+    def dec_layer_full(self, i: int, x: torch.Tensor, S_img: int) -> torch.Tensor:
+        """One decoder layer over [image ; text] rows x [B, S_img + T, D] with the GIT block mask (the loop body of decoder_full)."""
+        rows = torch.arange(x.shape[1])
+        klimit = torch.where(rows < S_img, torch.full_like(rows, S_img), rows + 1)
+        k, v = self._kv(i, x)
+        return self._dec_layer(i, x, k, v, klimit)
+
+    def dec_layer_img(self, i: int, x: torch.Tensor) -> torch.Tensor:
+        """One decoder layer over image rows only, x [B, S_img, D] (image rows never see text): the loop body of image_kv."""
+        S_img = x.shape[1]
+        k, v = self._kv(i, x, True)
+        return self._dec_layer(i, x, k, v, torch.full((S_img,), S_img), True)
 
     def decoder_full(self, memory: torch.Tensor, ids: torch.Tensor,
                      return_hidden: bool = False):

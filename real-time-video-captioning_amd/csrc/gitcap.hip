@@ -12,7 +12,9 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
+#include <sched.h>
 
 #define GITCAP_ABI_VERSION 1
 // (tools/build_diag.py redefines this to reach the experimental tile kernels of tools/experiments/)
@@ -148,6 +150,7 @@ struct gitcap {
         // device-resident beam-search state of the slot (gitcap_beam_search / _submit)
         BeamBuffers beam{}; float* beam_logits = nullptr; float* cand_scores = nullptr; int* cand_idx = nullptr; char* topk_scratch = nullptr;
         int B = 0, S = 0; bool have = false, used = false;
+        int Mt = 0;             // text rows (rows x positions) the slot's row workspace holds
         hipEvent_t ev_in = nullptr, ev_enc = nullptr, ev_dec = nullptr;
         hipStream_t s_txt = nullptr;
     };
@@ -543,6 +546,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     if (t0 + T > h->Tmax) return fail(h, GITCAP_ERR_ARG, "text_forward: t0+T exceeds max_text_len");
     if (t0 + T > c.max_text_pos) return fail(h, GITCAP_ERR_ARG, "text_forward: position exceeds max_text_pos");
     const int D = h->D, M = rows * T, H = c.dec_heads;
+    if (M > h->slots[h->cur_slot].Mt) return fail(h, GITCAP_ERR_STATE, "text_forward: more text rows than the slot's workspace holds");
     int rc;
     const size_t kvi_layer = (size_t)h->Mi * 3 * D, kvt_layer = (size_t)h->R * h->Tmax * 3 * D;
     // FC1 -> GELU -> FC2 of the text rows: one launch over 64-wide hidden slices (ffn_txt.hip), leaving dec_ffn / 64 fp32
@@ -755,7 +759,7 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     const int Dm = std::max(h->Dv, h->D), Fm = std::max(c.enc_ffn, c.dec_ffn);
     h->nslab_max = std::max(16, std::min(64, c.dec_ffn / 64));    // FC2 partial slabs per text row: dec_ffn / 64 hidden slices (ffn_txt.hip)
     int rc = 0;
-    const size_t Mi = h->Mi, Mt = h->Mt;
+    const size_t Mi = h->Mi;
     rc = rc ? rc : ws_alloc(h, &h->x, Mi * Dm);
     rc = rc ? rc : ws_alloc(h, &h->tmp, Mi * h->D);
     rc = rc ? rc : ws_alloc(h, &h->ln_stats, Mi * 16);
@@ -777,6 +781,11 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
         if (i == 0) sl.kv_img = h->kv_img;
         else rc = rc ? rc : ws_alloc(h, &sl.kv_img, (size_t)c.dec_layers * Mi * 3 * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.sep_cnt, (size_t)h->Tmax + 1);
+        // Text-row workspace (48 fp32 FC2 slabs + 12 per-head partials = 184 KB per row, the arg-max partials, ...): slot 0 also
+        // serves the synchronous entry points, whose teacher-forced passes run rows x positions text rows at once; slots 1-3 only
+        // ever run token loops of pipelined submissions -- one position per row and step -- and are sized for that.
+        const size_t Mt = i == 0 ? (size_t)h->Mt : (size_t)pad_to(h->R, 16);
+        sl.Mt = (int)Mt;
         rc = rc ? rc : ws_alloc(h, &sl.xs, Mt * h->D);
         rc = rc ? rc : ws_alloc(h, &sl.xs2, 2 * h->D);            // second copy of the residual rows for the one/two-row form
         rc = rc ? rc : ws_alloc(h, &sl.slabs, (size_t)h->nslab_max * Mt * h->D);
@@ -1472,7 +1481,8 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
 // 6: polls a fused GEMM + LayerNorm tile waits for its siblings before it gives up (0 = default; 1 forces the fail-soft path),
 // 7: text rows' FC1 -> GELU -> FC2 as one launch over hidden slices (ffn_txt.hip) on/off,
 // 8: gitcap_finalize_weights makes fragment-major copies of the text-path weights on/off (takes effect at the next finalize),
-// 9: text attention launches of more units than CUs use 8-wave workgroups (two units per CU) on/off.
+// 9: text attention launches of more units than CUs use 8-wave workgroups (two units per CU) on/off,
+// 10 / 11: see include/gitcap.h, 12: the 256x256 GEMM's K loop with four barriers per K-tile instead of eight on/off.
 // Returns the old value.
 int gitcap_dbg_config(int key, int value) {
     int old = -1;
@@ -1489,6 +1499,7 @@ int gitcap_dbg_config(int key, int value) {
         case 9: old = g_txt8.exchange(value != 0); break;
         case 10: old = g_head_share.exchange(value != 0); break;
         case 11: old = g_rows3.exchange(value != 0); break;
+        case 12: old = g_gemm_s4.exchange(value != 0); break;
         default: return GITCAP_ERR_ARG;
     }
     return old;
@@ -1502,6 +1513,57 @@ int gitcap_dbg_layernorm(const float* x, const float* gamma, const float* beta, 
                          float* out_f32, void* out_bf16, void* stream) {
     LnArgs a{x, D, gamma, beta, eps, rows, D, out_f32, D, (bf16_t*)out_bf16, D, nullptr, 1, 1, nullptr, nullptr, 0.f};
     return launch_layernorm(a, (hipStream_t)stream) == hipSuccess ? 0 : GITCAP_ERR_HIP;
+}
+
+// Threads a host-side copy may use: the affinity mask capped by the cgroup CPU quota (a 1-GPU box gives the job a share of the
+// host: a pool as wide as the machine only time-slices against itself), at most 8 (a copy is memory bound long before that).
+static int host_copy_threads() {
+    static const int n = [] {
+        int c = 0;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) c = CPU_COUNT(&set);
+        if (c <= 0) c = (int)std::thread::hardware_concurrency();
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0}; long per = 0;
+            if (fscanf(f, "%31s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) {
+                const long quota = atol(q);
+                if (quota > 0) c = std::min(c, std::max(1, (int)((quota + per / 2) / per)));
+            }
+            fclose(f);
+        }
+        if (getenv("GITCAP_HOST_COPY_THREADS")) c = atoi(getenv("GITCAP_HOST_COPY_THREADS"));
+        return std::max(1, std::min(8, c));
+    }();
+    return n;
+}
+
+int gitcap_host_copy(void* dst, const void* src, int64_t bytes) {
+    if ((!dst || !src) && bytes > 0) return GITCAP_ERR_ARG;
+    if (bytes <= 0) return bytes == 0 ? 0 : GITCAP_ERR_ARG;
+    const int64_t piece = (int64_t)4 << 20;                        // below 4 MiB per thread a second thread does not pay
+    int nt = (int)std::min<int64_t>(host_copy_threads(), (bytes + piece - 1) / piece);
+    if (nt <= 1) { memcpy(dst, src, (size_t)bytes); return 0; }
+    const int64_t chunk = ((bytes + nt - 1) / nt + 4095) & ~(int64_t)4095;
+    std::vector<std::thread> th;
+    th.reserve(nt - 1);
+    int started = 0;
+    try {
+        for (int i = 1; i < nt; ++i) {
+            const int64_t o = chunk * i;
+            if (o >= bytes) break;
+            th.emplace_back([=] { memcpy((char*)dst + o, (const char*)src + o, (size_t)std::min(chunk, bytes - o)); });
+            ++started;
+        }
+    } catch (...) {                                                 // no thread to be had: the caller's thread copies the rest
+        for (auto& t : th) t.join();
+        const int64_t o = chunk * (started + 1);
+        memcpy(dst, src, (size_t)std::min(chunk, bytes));
+        if (o < bytes) memcpy((char*)dst + o, (const char*)src + o, (size_t)(bytes - o));
+        return 0;
+    }
+    memcpy(dst, src, (size_t)std::min(chunk, bytes));
+    for (auto& t : th) t.join();
+    return 0;
 }
 
 int gitcap_dbg_enc_tap(gitcap_t* h, float* buf) {

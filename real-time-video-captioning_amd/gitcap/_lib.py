@@ -41,6 +41,7 @@ SYMBOLS = {
     "gitcap_beam_search_raw_submit": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_float, c_int,
                                               c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
     "gitcap_dbg_enc_tap": (c_int, [c_void_p, c_void_p]),
+    "gitcap_host_copy": (c_int, [c_void_p, c_void_p, c_int64]),
     "gitcap_poll_errors": (c_int, [c_void_p]),
     "gitcap_preprocess": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "gitcap_beam_topk": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

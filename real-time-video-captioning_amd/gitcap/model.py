@@ -18,6 +18,7 @@ in the hand-written gfx950 kernels behind the C ABI (include/gitcap.h).
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 from typing import Dict, Mapping, Optional
 
@@ -75,14 +76,26 @@ class _StagingRing:
     and the host waits for the entry's previous host -> device copy before touching the pinned buffer."""
     DEPTH = 4
 
-    def __init__(self, dev):
-        self.dev = dev
-        self.stream = torch.cuda.Stream(device=dev)
+    def __init__(self, dev, lib, own_stream=True):
+        self.dev, self.lib = dev, lib
+        # own_stream=False: the copies go on the caller's current stream (the runtime multiplexes streams onto a few hardware
+        # queues: a fifth stream beside the caller's, the encoder's and the two decode streams may share a queue with one of them)
+        self.stream = torch.cuda.Stream(device=dev) if own_stream else None
         self.entries = [dict(pinned=None, device=None, ev=None, sub=None) for _ in range(self.DEPTH + 1)]   # [-1]: synchronous calls
         self.n = 0
 
-    def stream_ptr(self):
-        return ctypes.c_void_p(self.stream.cuda_stream)
+    def copy_stream(self):
+        return self.stream if self.stream is not None else torch.cuda.current_stream(self.dev)
+
+    def _host_copy(self, dst, src):
+        """src (CPU tensor, any memory) -> dst (a view of the pinned buffer, same shape)."""
+        if src.dtype == dst.dtype and src.is_contiguous():
+            nbytes = src.numel() * src.element_size()
+            rc = self.lib.gitcap_host_copy(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), nbytes)
+            if rc != 0:
+                raise _lib.GitcapError(f"gitcap_host_copy failed (status {rc})")
+        else:
+            dst.copy_(src)                            # strided or another dtype: ATen's copy converts
 
     @staticmethod
     def _grow(e, nbytes, dev):
@@ -99,7 +112,7 @@ class _StagingRing:
         e = self.entries[-1] if sync else self.entries[self.n % self.DEPTH]
         if not sync:
             self.n += 1
-        st = stream if sync else self.stream
+        st = stream if sync else self.copy_stream()
         rows = sum(p.shape[0] for p in parts)
         shape = (rows,) + tuple(parts[0].shape[1:])
         nbytes = rows * int(np.prod(parts[0].shape[1:])) * torch.empty((), dtype=dtype).element_size()
@@ -124,14 +137,14 @@ class _StagingRing:
             hsrc = e["pinned"][:nbytes].view(dtype).view(shape)
             r0 = 0
             for p in parts:
-                hsrc[r0:r0 + p.shape[0]].copy_(p)     # (ATen's parallel CPU copy; converts the dtype if it has to)
+                self._host_copy(hsrc[r0:r0 + p.shape[0]], p)
                 r0 += p.shape[0]
         with torch.cuda.stream(st):
             dview.copy_(hsrc, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(st)
         e["ev"] = ev
-        return dview, e
+        return dview, e, st
 
 
 class _Future:
@@ -275,6 +288,7 @@ class GitCaptioner(nn.Module):
         self._inflight = []                             # submissions whose wait has not been enqueued yet (<= 4)
         self._undelivered = set()                       # waited for, but a future has still to hand out (or re-run) its rows
         self._ring = None                               # _StagingRing, made when the first CPU tensor arrives
+        self._copy_stream = os.environ.get("GITCAP_COPY_STREAM", "own")     # "own" | "caller" (A/B switch; see _StagingRing)
         self._lib = _lib.load()                         # raises if libgitcap.so is missing
         self._create()
         if weights is not None:
@@ -326,7 +340,7 @@ class GitCaptioner(nn.Module):
 
     def _staging(self):
         if self._ring is None:
-            self._ring = _StagingRing(self._dev)
+            self._ring = _StagingRing(self._dev, self._lib, own_stream=self._copy_stream == "own")
         return self._ring
 
     def _submit(self, name, *args):
@@ -478,7 +492,7 @@ class GitCaptioner(nn.Module):
         dtype = torch.uint8 if x.dtype == torch.uint8 else torch.float32
         if x.device.type == "cpu":
             with torch.cuda.device(self._dev):
-                dv, _ = self._staging().stage(self, [x], dtype, stream=torch.cuda.current_stream(self._dev))
+                dv, _, _ = self._staging().stage(self, [x], dtype, stream=torch.cuda.current_stream(self._dev))
             return dv
         x = x.to(device=self._dev, dtype=dtype).contiguous()
         if x.data_ptr() % 16:
@@ -737,9 +751,8 @@ class GitCaptioner(nn.Module):
     def _stage_group(self, parts, raw):
         """Host-fed submission: the callers' CPU tensors -> one ring entry (pinned staging unless the single tensor is already
         page-locked) -> device, on the copy stream.  Returns (device frames, ring entry, stream the submission is ordered behind)."""
-        ring = self._staging()
-        dv, entry = ring.stage(self, parts, torch.uint8 if raw else torch.float32)
-        return dv, entry, ring.stream_ptr()
+        dv, entry, st = self._staging().stage(self, parts, torch.uint8 if raw else torch.float32)
+        return dv, entry, ctypes.c_void_p(st.cuda_stream)
 
     def _flush_pending(self):
         """Submit the waiting batches as one pass and hand each future its row range."""
