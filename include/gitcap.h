@@ -225,9 +225,10 @@ int gitcap_beam_search_wait(gitcap_t* h, int ticket, void* stream);
  * gitcap_greedy_raw): the transform of src/utils/dataloader.py:18-32 / src/real_time_inference.py:16-28 fused with the patch
  * gather runs as the first launch of the image pass on the handle's encoder stream.  This is the form a HOST-fed caller uses
  * (src/real_time_inference.py:39-58 holds OpenCV frames in host memory; src/inference.py:45-51 a DataLoader's CPU tensor): the
- * caller copies batch i + 1 to the device on a copy stream of its own (a quarter of the bytes of the fp32 tensor) and passes
- * THAT stream as `stream`, so the copy runs under batch i's compute and only the image pass waits for it
- * (gitcap/model.py: _StagingRing is that caller).  Results are bitwise those of gitcap_greedy_raw / of gitcap_preprocess +
+ * caller enqueues the copy of batch i + 1 (a quarter of the bytes of the fp32 tensor) on the stream it passes as `stream`, so the
+ * copy runs under batch i's compute and only the image pass waits for it (gitcap/model.py: _StagingRing is that caller; keep to
+ * the caller's own stream -- with a fifth stream the runtime's four hardware queues are oversubscribed and a copy queues behind
+ * a token loop: measured 1 618 against 2 004 captions/s, profiles/r06_host_fed_copy_stream.txt).  Results are bitwise those of gitcap_greedy_raw / of gitcap_preprocess +
  * gitcap_beam_search.  Tickets, slots and waits as for gitcap_greedy_submit. */
 int gitcap_greedy_raw_submit(gitcap_t* h, const uint8_t* frames_hwc_bgr, int B, int F, int H, int W, int max_len, int stop,
                              int64_t* ids_out, int32_t* steps_out, void* stream, int* ticket);
@@ -301,8 +302,7 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
  * FC1 -> GELU -> FC2 as one launch over hidden slices on/off; 8: fragment-major copies of the text-path weights at the next
  * gitcap_finalize_weights on/off; 9: 8-wave workgroups for text-attention launches of more (row, head) units than CUs on/off;
  * 10: the vocabulary head's four-tile workgroups that share the activation rows through LDS on/off; 11: three-wave workgroups
- * that share the slab reduce of the one/two-row prologue on/off; 12: the 256x256 GEMM's K loop with four barriers per K-tile instead of
- * eight on/off.  Returns the previous value (< 0: bad key).  The switches are process-wide atomics: a call on another thread sees either value,
+ * that share the slab reduce of the one/two-row prologue on/off.  Returns the previous value (< 0: bad key).  The switches are process-wide atomics: a call on another thread sees either value,
  * and either value gives the same bits. */
 int gitcap_dbg_config(int key, int value);
 /* attn_full: qkv [G*S][3*H*64] bf16 -> ctx [G*S][H*64] bf16 */

@@ -36,10 +36,6 @@
 // ds_read_b128 for the 16x16x32 operand map, see common.h).
 #include "gemm_epilogue.h"
 #include "host_logic.h"
-#include <cstdlib>
-
-// K loop with four barriers per K-tile (S4, below) instead of eight: GITCAP_GEMM_S4=0|1 / gitcap_dbg_config(12, .).  Same bits.
-std::atomic<bool> g_gemm_s4{getenv("GITCAP_GEMM_S4") ? atoi(getenv("GITCAP_GEMM_S4")) != 0 : false};
 
 namespace {
 
@@ -51,21 +47,7 @@ constexpr int LDS_TOTAL = 8 * EPI_REGION;        // 139264 B >= 2 * STAGE
 #define WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-// S4: the K loop with FOUR barriers per K-tile instead of eight (round 6; speed switch 12): the same MFMAs on the same operands in
-// the same order per accumulator -- the same bits -- in compute phases of two quadrants (32 MFMAs) each:
-//
-//     slot      4t+0    4t+1    4t+2    4t+3    4t+4
-//     group 0   LA(t)   CA(t)   LB(t)   CB(t)   LA(t+1)
-//     group 1   CB(t-1) LA(t)   CA(t)   LB(t)   CB(t)
-//
-//   LA: read act frags M0, M1 (8)                           CA (N0,M0)(N0,M1): + read W frags N1 (8)
-//   LB: LDS-DMA (below)                                     CB (N1,M1)(N1,M0): + read W frags N0 of tile t+1 (8)
-// A group reads only "its" W half (wn = group) and both A halves; stage t & 1 is read in slots 4t-1 .. 4t+1 by group 0 and
-// 4t .. 4t+2 by group 1, so W-lo(t) is dead after slot 4t+1 and W-hi(t), A(t) after slot 4t+2.  LDS-DMA of tile t+2 into that stage:
-//   group 0: LB(t) [4t+2]: W-lo(t+2);   LA(t+1) [4t+4]: W-hi, A-lo, A-hi (t+2)        group 1: LB(t) [4t+3]: all of tile t+2
-// First reads of tile t+1: W-lo in CB(t) of group 0 [4t+3], A in LA(t+1) [4t+4], W-hi in CB(t) of group 1 [4t+4]; every wave retires
-// its own pieces with a counted vmcnt one barrier earlier (group 0: end of LB(t) and of CB(t); group 1: end of CA(t) and of LB(t)).
-template <int EPI, bool LN8 = false, bool S4 = false>
+template <int EPI, bool LN8 = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -136,273 +118,148 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
     // later, in C3(t) (W-lo rows of tile t+1) and L0(t+1).
     const int nt = a.K >> 6;
     LN_STAMP(0);
-    if constexpr (!S4) {
-    #pragma unroll
-        for (int w = 0; w < 4; ++w) dma_half(smem, w, 0);
-        if (nt > 1) {
-            dma_half(smem + STAGE, 2, 64);
-            dma_half(smem + STAGE, 3, 64);
-            dma_half(smem + STAGE, 0, 64);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) dma_half(smem, w, 0);
+    if (nt > 1) {
+        dma_half(smem + STAGE, 2, 64);
+        dma_half(smem + STAGE, 3, 64);
+        dma_half(smem + STAGE, 0, 64);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        WAIT_VM0();
+    }
+    BARRIER();
+    if (grp == 1) BARRIER();                       // group 1 runs one slot behind group 0
+
+    // Fragment reads are issued one COMPUTE phase ahead of their use (LDS reads between MFMAs are nearly
+    // free), so the LOAD phases only issue LDS-DMA and drain lgkmcnt:
+    //   C0 (N0,M0): + read M1        C1 (N0,M1): + read N1 -> wf2      C2 (N1,M1)
+    //   C3 (N1,M0): + read N0 of tile t+1 -> wf (valid: C3 follows the vmcnt wait + barrier of L3)
+    //   L0: read M0 of this tile (its registers are still in use during the previous C3)
+    bf16x8 wf[4][2], wf2[4][2], af[2][2][2];
+    {
+        const char* sb0 = smem;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wf[i][0] = *(const bf16x8*)(sb0 + offW + i * 2048 + c0);
+            wf[i][1] = *(const bf16x8*)(sb0 + offW + i * 2048 + c1);
+        }
+    }
+    for (int t = 0; t < nt; ++t) {
+        const char* sb = smem + (t & 1) * STAGE;
+        char* cb = smem + (t & 1) * STAGE;          // stage of tile t == stage of tile t+2
+        char* nb = smem + ((t + 1) & 1) * STAGE;
+        const bool has1 = (t + 1) < nt, has2 = (t + 2) < nt;
+        const int k1 = (t + 1) << 6, k2 = (t + 2) << 6;
+
+        // ---------------- L0: act rows M0 ----------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            af[0][j][0] = *(const bf16x8*)(sb + offA + j * 2048 + c0);
+            af[0][j][1] = *(const bf16x8*)(sb + offA + j * 2048 + c1);
+        }
+        WAIT_LGKM0();
+        SCHED_FENCE();
+        BARRIER();
+        // ---------------- C0: (N0, M0); prefetch M1 ------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            af[1][j][0] = *(const bf16x8*)(sb + offA + 32 * 128 + j * 2048 + c0);
+            af[1][j][1] = *(const bf16x8*)(sb + offA + 32 * 128 + j * 2048 + c1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[0][i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], af[0][j][ks], acc[0][i][0][j], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        }
+        __builtin_amdgcn_s_setprio(0);
+        SCHED_FENCE();
+        BARRIER();
+        // ---------------- L1: DMA W-hi of tile t+1 --------------------------------------------------
+        if (has1) dma_half(nb, 1, k1);
+        WAIT_LGKM0();
+        SCHED_FENCE();
+        BARRIER();
+        // ---------------- C1: (N0, M1); prefetch N1 -------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wf2[i][0] = *(const bf16x8*)(sb + offW + 64 * 128 + i * 2048 + c0);
+            wf2[i][1] = *(const bf16x8*)(sb + offW + 64 * 128 + i * 2048 + c1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[0][i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], af[1][j][ks], acc[0][i][1][j], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        }
+        __builtin_amdgcn_s_setprio(0);
+        SCHED_FENCE();
+        BARRIER();
+        // ---------------- L2: DMA A-lo of tile t+2 ---------------------------------------------------
+        if (has2) dma_half(cb, 2, k2);
+        WAIT_LGKM0();
+        SCHED_FENCE();
+        BARRIER();
+        // ---------------- C2: (N1, M1) ---------------------------------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[1][i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[i][ks], af[1][j][ks], acc[1][i][1][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        SCHED_FENCE();
+        BARRIER();
+        // ---------------- L3: DMA A-hi, W-lo of tile t+2; retire tile t+1 ---------------------------
+        if (has2) {
+            dma_half(cb, 3, k2);
+            dma_half(cb, 0, k2);
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         } else {
             WAIT_VM0();
         }
+        SCHED_FENCE();
         BARRIER();
-        if (grp == 1) BARRIER();                       // group 1 runs one slot behind group 0
-
-        // Fragment reads are issued one COMPUTE phase ahead of their use (LDS reads between MFMAs are nearly
-        // free), so the LOAD phases only issue LDS-DMA and drain lgkmcnt:
-        //   C0 (N0,M0): + read M1        C1 (N0,M1): + read N1 -> wf2      C2 (N1,M1)
-        //   C3 (N1,M0): + read N0 of tile t+1 -> wf (valid: C3 follows the vmcnt wait + barrier of L3)
-        //   L0: read M0 of this tile (its registers are still in use during the previous C3)
-        bf16x8 wf[4][2], wf2[4][2], af[2][2][2];
-        {
-            const char* sb0 = smem;
-    #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wf[i][0] = *(const bf16x8*)(sb0 + offW + i * 2048 + c0);
-                wf[i][1] = *(const bf16x8*)(sb0 + offW + i * 2048 + c1);
-            }
-        }
-        for (int t = 0; t < nt; ++t) {
-            const char* sb = smem + (t & 1) * STAGE;
-            char* cb = smem + (t & 1) * STAGE;          // stage of tile t == stage of tile t+2
-            char* nb = smem + ((t + 1) & 1) * STAGE;
-            const bool has1 = (t + 1) < nt, has2 = (t + 2) < nt;
-            const int k1 = (t + 1) << 6, k2 = (t + 2) << 6;
-
-            // ---------------- L0: act rows M0 ----------------------------------------------------------
-    #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                af[0][j][0] = *(const bf16x8*)(sb + offA + j * 2048 + c0);
-                af[0][j][1] = *(const bf16x8*)(sb + offA + j * 2048 + c1);
-            }
-            WAIT_LGKM0();
-            SCHED_FENCE();
-            BARRIER();
-            // ---------------- C0: (N0, M0); prefetch M1 ------------------------------------------------
-            __builtin_amdgcn_s_setprio(1);
-    #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                af[1][j][0] = *(const bf16x8*)(sb + offA + 32 * 128 + j * 2048 + c0);
-                af[1][j][1] = *(const bf16x8*)(sb + offA + 32 * 128 + j * 2048 + c1);
-            }
-    #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-    #pragma unroll
-                for (int i = 0; i < 4; ++i)
-    #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[0][i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], af[0][j][ks], acc[0][i][0][j], 0, 0, 0);
-    #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-            }
-            __builtin_amdgcn_s_setprio(0);
-            SCHED_FENCE();
-            BARRIER();
-            // ---------------- L1: DMA W-hi of tile t+1 --------------------------------------------------
-            if (has1) dma_half(nb, 1, k1);
-            WAIT_LGKM0();
-            SCHED_FENCE();
-            BARRIER();
-            // ---------------- C1: (N0, M1); prefetch N1 -------------------------------------------------
-            __builtin_amdgcn_s_setprio(1);
-    #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wf2[i][0] = *(const bf16x8*)(sb + offW + 64 * 128 + i * 2048 + c0);
-                wf2[i][1] = *(const bf16x8*)(sb + offW + 64 * 128 + i * 2048 + c1);
-            }
-    #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-    #pragma unroll
-                for (int i = 0; i < 4; ++i)
-    #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[0][i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], af[1][j][ks], acc[0][i][1][j], 0, 0, 0);
-    #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-            }
-            __builtin_amdgcn_s_setprio(0);
-            SCHED_FENCE();
-            BARRIER();
-            // ---------------- L2: DMA A-lo of tile t+2 ---------------------------------------------------
-            if (has2) dma_half(cb, 2, k2);
-            WAIT_LGKM0();
-            SCHED_FENCE();
-            BARRIER();
-            // ---------------- C2: (N1, M1) ---------------------------------------------------------------
-            __builtin_amdgcn_s_setprio(1);
-    #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-    #pragma unroll
-                for (int i = 0; i < 4; ++i)
-    #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[1][i][1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[i][ks], af[1][j][ks], acc[1][i][1][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            SCHED_FENCE();
-            BARRIER();
-            // ---------------- L3: DMA A-hi, W-lo of tile t+2; retire tile t+1 ---------------------------
-            if (has2) {
-                dma_half(cb, 3, k2);
-                dma_half(cb, 0, k2);
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            } else {
-                WAIT_VM0();
-            }
-            SCHED_FENCE();
-            BARRIER();
-            // ---------------- C3: (N1, M0); prefetch N0 of tile t+1 --------------------------------------
-            __builtin_amdgcn_s_setprio(1);
-            // (on the last tile this reads the other stage's stale image: in bounds, never used)
-    #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wf[i][0] = *(const bf16x8*)(nb + offW + i * 2048 + c0);
-                wf[i][1] = *(const bf16x8*)(nb + offW + i * 2048 + c1);
-            }
-    #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-    #pragma unroll
-                for (int i = 0; i < 4; ++i)
-    #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[1][i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[i][ks], af[0][j][ks], acc[1][i][0][j], 0, 0, 0);
-    #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-            }
-            __builtin_amdgcn_s_setprio(0);
-            SCHED_FENCE();
-            BARRIER();
-        }
-    } else {
-        // ---- four barriers per K-tile (see the comment above the kernel) ----
-        bf16x8 wf[4][2], wf2[4][2], af[2][2][2];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) dma_half(smem, w, 0);
-        if (nt > 1) {
-            // tile 1: group 0 holds back nothing here (its W-hi / A pieces of tile t+1 are issued in LA(t) from t = 1 on)
-            dma_half(smem + STAGE, 0, 64);
-            dma_half(smem + STAGE, 1, 64);
-            dma_half(smem + STAGE, 2, 64);
-            dma_half(smem + STAGE, 3, 64);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-            WAIT_VM0();
-        }
-        BARRIER();
-        if (grp == 1) BARRIER();                   // group 1 runs one slot behind group 0
+        // ---------------- C3: (N1, M0); prefetch N0 of tile t+1 --------------------------------------
+        __builtin_amdgcn_s_setprio(1);
+        // (on the last tile this reads the other stage's stale image: in bounds, never used)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            wf[i][0] = *(const bf16x8*)(smem + offW + i * 2048 + c0);
-            wf[i][1] = *(const bf16x8*)(smem + offW + i * 2048 + c1);
+            wf[i][0] = *(const bf16x8*)(nb + offW + i * 2048 + c0);
+            wf[i][1] = *(const bf16x8*)(nb + offW + i * 2048 + c1);
         }
-        for (int t = 0; t < nt; ++t) {
-            const char* sb = smem + (t & 1) * STAGE;
-            char* cb = smem + (t & 1) * STAGE;      // stage of tile t == stage of tile t+2
-            char* nb = smem + ((t + 1) & 1) * STAGE;
-            const bool has1 = (t + 1) < nt, has2 = (t + 2) < nt;
-            const int k1 = (t + 1) << 6, k2 = (t + 2) << 6;
-
-            // ---------------- LA: act rows M0, M1; group 0: W-hi, A-lo, A-hi of tile t+1 (t >= 1) ------
 #pragma unroll
-            for (int y = 0; y < 2; ++y)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    af[y][j][0] = *(const bf16x8*)(sb + offA + y * 32 * 128 + j * 2048 + c0);
-                    af[y][j][1] = *(const bf16x8*)(sb + offA + y * 32 * 128 + j * 2048 + c1);
-                }
-            if (grp == 0 && t >= 1 && has1) {
-                dma_half(nb, 1, k1);
-                dma_half(nb, 2, k1);
-                dma_half(nb, 3, k1);
-            }
-            WAIT_LGKM0();
-            SCHED_FENCE();
-            BARRIER();
-            // ---------------- CA: (N0, M0) (N0, M1); prefetch N1 ------------------------------------------
-            __builtin_amdgcn_s_setprio(1);
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wf2[i][0] = *(const bf16x8*)(sb + offW + 64 * 128 + i * 2048 + c0);
-                wf2[i][1] = *(const bf16x8*)(sb + offW + 64 * 128 + i * 2048 + c1);
-            }
+                for (int j = 0; j < 2; ++j)
+                    acc[1][i][0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[i][ks], af[0][j][ks], acc[1][i][0][j], 0, 0, 0);
 #pragma unroll
-            for (int y = 0; y < 2; ++y)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[0][i][y][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i][ks], af[y][j][ks], acc[0][i][y][j], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {              // N1 fragments between the MFMAs (used in CB)
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-            __builtin_amdgcn_s_setprio(0);
-            WAIT_LGKM0();                               // (WAR: the stage is overwritten from the next slot on)
-            if (grp == 1 && has1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // its W-lo pieces of tile t+1
-            SCHED_FENCE();
-            BARRIER();
-            // ---------------- LB: DMA of tile t+2 (group 0: W-lo; group 1: everything) --------------------
-            if (grp == 0) {
-                if (has2) { dma_half(cb, 0, k2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }   // its W-lo pieces of tile t+1 retired
-                else if (has1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            } else {
-                if (has2) {
-                    dma_half(cb, 0, k2);
-                    dma_half(cb, 1, k2);
-                    dma_half(cb, 2, k2);
-                    dma_half(cb, 3, k2);
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                  // all of tile t+1 retired
-                } else {
-                    WAIT_VM0();
-                }
-            }
-            SCHED_FENCE();
-            BARRIER();
-            // ---------------- CB: (N1, M1) (N1, M0); prefetch N0 of tile t+1 ------------------------------
-            __builtin_amdgcn_s_setprio(1);
-            // (on the last tile this reads the other stage's stale image: in bounds, never used)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wf[i][0] = *(const bf16x8*)(nb + offW + i * 2048 + c0);
-                wf[i][1] = *(const bf16x8*)(nb + offW + i * 2048 + c1);
-            }
-#pragma unroll
-            for (int y = 1; y >= 0; --y)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[1][i][y][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[i][ks], af[y][j][ks], acc[1][i][y][j], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-            __builtin_amdgcn_s_setprio(0);
-            WAIT_LGKM0();
-            if (grp == 0) {                             // its W-hi / A pieces of tile t+1 (issued in LA(t); in the prologue for t = 0)
-                if (has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                else WAIT_VM0();
-            }
-            SCHED_FENCE();
-            BARRIER();
+        for (int q = 0; q < 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
         }
+        __builtin_amdgcn_s_setprio(0);
+        SCHED_FENCE();
+        BARRIER();
     }
     if (grp == 0) BARRIER();                       // matches group 1's extra leading barrier
     LN_STAMP(1);
@@ -417,15 +274,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs a) {
 #endif
 }
 
-template <int EPI, bool LN8, bool S4>
-hipError_t launch_s(const GemmArgs& a0, hipStream_t s) {
+template <int EPI, bool LN8 = false>
+hipError_t launch_t(const GemmArgs& a0, hipStream_t s) {
     static bool attr_done[64] = {false};            // per device: the attribute belongs to the device's code object
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     bool& attr_set = attr_done[dev_ & 63];
     constexpr int LDS = (EPI == EPI_RESID_LN_PRE || EPI == EPI_RESID_LN_POST) ? LN_LDS_TOTAL : LDS_TOTAL;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, LN8, S4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<EPI, LN8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -436,13 +293,8 @@ hipError_t launch_s(const GemmArgs& a0, hipStream_t s) {
         a.ln_rowblock_map = ln_use_rowblock_map(a.M >> 8, a.N >> 8, device_cus()) ? 1 : 0;
         if (a.ln_rowblock_map) grid = ln_grid_size(a.M >> 8, a.N >> 8);
     }
-    hipLaunchKernelGGL((gemm256_kernel<EPI, LN8, S4>), dim3(grid), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, LN8>), dim3(grid), dim3(512), LDS, s, a);
     return hipGetLastError();
-}
-
-template <int EPI, bool LN8 = false>
-hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
-    return g_gemm_s4 ? launch_s<EPI, LN8, true>(a, s) : launch_s<EPI, LN8, false>(a, s);
 }
 
 }  // namespace

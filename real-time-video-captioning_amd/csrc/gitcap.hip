@@ -1482,7 +1482,7 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
 // 7: text rows' FC1 -> GELU -> FC2 as one launch over hidden slices (ffn_txt.hip) on/off,
 // 8: gitcap_finalize_weights makes fragment-major copies of the text-path weights on/off (takes effect at the next finalize),
 // 9: text attention launches of more units than CUs use 8-wave workgroups (two units per CU) on/off,
-// 10 / 11: see include/gitcap.h, 12: the 256x256 GEMM's K loop with four barriers per K-tile instead of eight on/off.
+// 10 / 11: see include/gitcap.h.
 // Returns the old value.
 int gitcap_dbg_config(int key, int value) {
     int old = -1;
@@ -1499,7 +1499,6 @@ int gitcap_dbg_config(int key, int value) {
         case 9: old = g_txt8.exchange(value != 0); break;
         case 10: old = g_head_share.exchange(value != 0); break;
         case 11: old = g_rows3.exchange(value != 0); break;
-        case 12: old = g_gemm_s4.exchange(value != 0); break;
         default: return GITCAP_ERR_ARG;
     }
     return old;

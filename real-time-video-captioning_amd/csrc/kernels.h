@@ -54,7 +54,6 @@ constexpr unsigned LN_SPIN_DEFAULT = 1u << 26;
 int device_cus();                 // compute units of the current device (cached per device; 256 when the query fails)
 hipError_t launch_gemm(const GemmArgs& a, int epi, hipStream_t s);      // 128x128 tile (any M%128, N%128)
 hipError_t launch_gemm64(const GemmArgs& a, int epi, hipStream_t s);    // 64x64 tile, 3-stage ring (few-hundred-row launches)
-extern std::atomic<bool> g_gemm_s4;                                      // gemm256.hip: four barriers per K-tile (speed switch 12)
 bool gemm256_ok(const GemmArgs& a);
 hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);   // 256x256 tile, 8-wave ping-pong
 bool gemm256_ln_ok(const GemmArgs& a);                                   // shape the EPI_RESID_LN_* epilogues accept

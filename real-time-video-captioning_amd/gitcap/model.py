@@ -66,21 +66,27 @@ class _Submission:
 
 class _StagingRing:
     """Host-fed submissions (the reference's callers hold CPU tensors: src/real_time_inference.py:39-58 OpenCV frames,
-    src/inference.py:45-51 a DataLoader batch): a ring of pinned host buffers + device buffers and ONE copy stream, so that the
-    host -> device copy of batch i + 1 runs under the compute of batch i.  The submission is made with the copy stream as its
-    `stream` argument (include/gitcap.h: gitcap_greedy_submit orders the image pass behind the work on that stream), so only the
-    image pass waits for the copy -- the caller's current stream never does.
+    src/inference.py:45-51 a DataLoader batch): a ring of pinned host buffers + device buffers, so that the host -> device copy
+    of batch i + 1 runs under the compute of batch i.  The copy is enqueued on the CALLER's current stream and the submission is
+    made behind it (include/gitcap.h: gitcap_greedy_submit orders the image pass behind the work already on `stream`): the
+    caller's stream carries nothing else but the waits for earlier results, so the copy starts at once, and only the image pass
+    waits for it.  (A stream of the ring's own -- own_stream=True, GITCAP_COPY_STREAM=own -- is a FIFTH stream beside the
+    caller's, the encoder's and the two decode streams; the runtime multiplexes streams onto four hardware queues, the copy then
+    queues behind a token loop and every image pass starts late: 1 618 instead of 2 004 captions/s host-fed,
+    profiles/r06_host_fed_copy_stream.txt -- the same effect as the fifth stream of round 3's two-encoder experiment.)
+
+    Pageable sources are copied into the pinned buffer by gitcap_host_copy (up to 8 threads, sized to the CPU quota: ATen's own
+    parallel copy sizes its pool to the whole machine and takes 20 ms per batch under a 16-core quota); page-locked sources
+    (DataLoader(pin_memory=True), a capture ring) are copied from where they are.
 
     Depth = the library's four slots.  An entry is reused four submissions later; before its device buffer is overwritten the
-    copy stream waits for the submission that read it (its `done_ev`, or the library's own wait while it is still in flight),
+    copy's stream waits for the submission that read it (its `done_ev`, or the library's own wait while it is still in flight),
     and the host waits for the entry's previous host -> device copy before touching the pinned buffer."""
     DEPTH = 4
 
-    def __init__(self, dev, lib, own_stream=True):
+    def __init__(self, dev, lib, own_stream=False):
         self.dev, self.lib = dev, lib
-        # own_stream=False: the copies go on the caller's current stream (the runtime multiplexes streams onto a few hardware
-        # queues: a fifth stream beside the caller's, the encoder's and the two decode streams may share a queue with one of them)
-        self.stream = torch.cuda.Stream(device=dev) if own_stream else None
+        self.stream = torch.cuda.Stream(device=dev) if own_stream else None      # None: the caller's current stream (see above)
         self.entries = [dict(pinned=None, device=None, ev=None, sub=None) for _ in range(self.DEPTH + 1)]   # [-1]: synchronous calls
         self.n = 0
 
@@ -106,7 +112,8 @@ class _StagingRing:
 
     def stage(self, model, parts, dtype, stream=None):
         """Copy the CPU tensors `parts` (same trailing shape; concatenated along dim 0) to the device.  stream=None: the
-        pipelined form on the copy stream, next ring entry; else the synchronous form on that (the caller's) stream.
+        pipelined form (next ring entry, the ring's copy stream = the caller's current stream by default); else the synchronous
+        form on that stream, in the entry of its own.
         Returns (device tensor, entry)."""
         sync = stream is not None
         e = self.entries[-1] if sync else self.entries[self.n % self.DEPTH]
@@ -288,7 +295,7 @@ class GitCaptioner(nn.Module):
         self._inflight = []                             # submissions whose wait has not been enqueued yet (<= 4)
         self._undelivered = set()                       # waited for, but a future has still to hand out (or re-run) its rows
         self._ring = None                               # _StagingRing, made when the first CPU tensor arrives
-        self._copy_stream = os.environ.get("GITCAP_COPY_STREAM", "own")     # "own" | "caller" (A/B switch; see _StagingRing)
+        self._copy_stream = os.environ.get("GITCAP_COPY_STREAM", "caller")  # "caller" | "own" (A/B switch; see _StagingRing)
         self._lib = _lib.load()                         # raises if libgitcap.so is missing
         self._create()
         if weights is not None:
@@ -719,9 +726,9 @@ class GitCaptioner(nn.Module):
 
         `src` may be transformed fp32 frames [B,F,3,S,S] or uint8 BGR camera frames [B,F,H,W,3] (the transform of
         dataloader.py:18-32 then runs on the device, fused with the patch gather), on the device or -- what the reference's
-        callers hold -- in HOST memory: a CPU tensor goes through a pinned staging ring and a copy stream, so its
-        host -> device copy runs under the compute of the batches before it (page-locked tensors, e.g. from
-        DataLoader(pin_memory=True), are copied from where they are).  A CPU tensor must not be modified before ``result()``.
+        callers hold -- in HOST memory: a CPU tensor goes through a pinned staging ring (_StagingRing), so its host -> device
+        copy runs under the compute of the batches before it (page-locked tensors, e.g. from DataLoader(pin_memory=True), are
+        copied from where they are).  A CPU tensor must not be modified before ``result()``.
 
         ``coalesce=k`` (dynamic batching): k consecutive calls with the same shape are concatenated and
         run as ONE pass of k*B clips (the per-clip results are bitwise the same: the kernels are batch
@@ -750,7 +757,7 @@ class GitCaptioner(nn.Module):
 
     def _stage_group(self, parts, raw):
         """Host-fed submission: the callers' CPU tensors -> one ring entry (pinned staging unless the single tensor is already
-        page-locked) -> device, on the copy stream.  Returns (device frames, ring entry, stream the submission is ordered behind)."""
+        page-locked) -> device.  Returns (device frames, ring entry, the stream the copy is on = what the submission is ordered behind)."""
         dv, entry, st = self._staging().stage(self, parts, torch.uint8 if raw else torch.float32)
         return dv, entry, ctypes.c_void_p(st.cuda_stream)
 

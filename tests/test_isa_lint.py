@@ -12,22 +12,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 # The expectations below (wait sequences, scratch bytes) describe the output of ONE compiler: they were taken with the hipcc of
-# ROCm 7.2 (HIP version 7.2.x).  On another major.minor the module is SKIPPED, not failed: a different schedule is then a reason
-# to re-read the listings (tools/isa_waits.py) and re-take the expectations, not a defect of the source.  The compile flags are
-# read from csrc/Makefile (tools/isa_waits.py: product_flags), so what is linted is what is shipped.
+# ROCm 7.2 (HIP version 7.2.x).  On another major.minor the checks still RUN, as expected failures (xfail, not strict): a different
+# schedule is then a reason to re-read the listings and re-take the expectations, not a defect of the source -- but the guard does
+# not go silent: the module prints the new wait sequences of every kernel it lints (pytest -rx shows them with the reason), and a
+# check that still passes is reported as XPASS.  Without hipcc there is nothing to run: skipped.  The compile flags are read from
+# csrc/Makefile (tools/isa_waits.py: product_flags), so what is linted is what is shipped.
 EXPECTED_HIPCC = "7.2"
+LINTED = (("ffn_txt.hip", "ffn_txt_kernelILi24ELb0"), ("ffn_txt.hip", "ffn_txt_kernelILi24ELb1"), ("gemm256.hip", "gemm256_kernelILi6E"),
+          ("gemm_f8.hip", "gemm256f8_kernelILi6E"), ("skinny.hip", "skinny_head_kernelILi24ELb0"), ("skinny.hip", "skinny_rows3_kernelILi24ELi0"))
 
 
-def _hipcc_ok():
+def _hipcc_state():
     if not os.path.exists("/opt/rocm/bin/hipcc"):
-        return False, "needs /opt/rocm/bin/hipcc"
+        return "missing", "needs /opt/rocm/bin/hipcc"
     from isa_waits import hipcc_version
     v = hipcc_version()
-    return v == EXPECTED_HIPCC, f"ISA expectations were taken with hipcc {EXPECTED_HIPCC}, this is {v}: re-take them (tools/isa_waits.py)"
+    if v == EXPECTED_HIPCC:
+        return "ok", ""
+    return "other", f"ISA expectations were taken with hipcc {EXPECTED_HIPCC}, this is {v}: re-take them from the sequences printed below (tools/isa_waits.py)"
 
 
-_ok, _why = _hipcc_ok()
-pytestmark = pytest.mark.skipif(not _ok, reason=_why)
+_state, _why = _hipcc_state()
+if _state == "missing":
+    pytestmark = pytest.mark.skip(reason=_why)
+elif _state == "other":
+    pytestmark = pytest.mark.xfail(reason=_why, strict=False)
 
 # kernels that are allowed a few dwords of scratch (the residual + LayerNorm epilogue of the 256 x 256 tile at 256 VGPRs), in bytes
 # (ILi6ELb1 / ILi7ELb1: the opt-in fp8-compute instantiations that also write and count the e4m3 copy of the LayerNorm output)
@@ -45,6 +54,12 @@ def listings():
         res, _ = kernel_listings(f, "_Z")
         assert res, f
         out[f] = res
+    if _state == "other":           # another compiler: show what it emits for the linted kernels instead of going silent
+        print("\n" + _why)
+        for f, pat in LINTED:
+            for name, vg, scratch, toks in out[f]:
+                if pat in name:
+                    print(f"{f}: {name}: {vg} VGPRs, {scratch} B scratch\n    " + " ".join(toks))
     return out
 
 
@@ -98,15 +113,15 @@ def test_gemm_ln_epilogue_keeps_its_spills_out_of_the_row_loops(listings):
     store), and the x stores of both half-blocks are waited for with counted waits (16 stores, first wait vmcnt(15))."""
     for f, pat in (("gemm256.hip", "gemm256_kernelILi6E"), ("gemm_f8.hip", "gemm256f8_kernelILi6E")):
         pres = [r for r in listings[f] if pat in r[0]]
-        assert len(pres) == 1, [r[0] for r in pres]                   # one pre-LN instantiation per tile kernel
-        toks = pres[0][3]
-        bs = toks.index("BS")
-        bars = [i for i, t in enumerate(toks[:bs]) if t == "|"]       # ... K loop | phase 1 | BS (the statistics publish)
-        phase1 = toks[bars[-2]:bs]
-        loops = phase1[phase1.index("W15"):]                          # from the first counted wait on: the two row loops
-        assert "xs" not in loops and "xl" not in loops, (pat, " ".join(phase1))
-        s = " ".join(phase1)
-        assert s.count("W15 S W14 S W13 S") == 2, (pat, s)
+        assert 1 <= len(pres) <= 2, [r[0] for r in pres]              # the pre-LN instantiation(s) of the tile kernel (gemm256: both K-loop forms)
+        for name, _, _, toks in pres:
+            bs = toks.index("BS")
+            bars = [i for i, t in enumerate(toks[:bs]) if t == "|"]       # ... K loop | phase 1 | BS (the statistics publish)
+            phase1 = toks[bars[-2]:bs]
+            loops = phase1[phase1.index("W15"):]                          # from the first counted wait on: the two row loops
+            assert "xs" not in loops and "xl" not in loops, (name, " ".join(phase1))
+            s = " ".join(phase1)
+            assert s.count("W15 S W14 S W13 S") == 2, (name, s)
 
 
 def test_vocabulary_head_requests_rows_ahead_of_weights(listings):

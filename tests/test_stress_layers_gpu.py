@@ -183,8 +183,12 @@ def test_gemm_ln_outlier_operands(M, N, K, post):
 def test_attn_full_peaked_scores(G, S, H):
     """attn_full on stress-shaped q|k|v: head 0's q and k x 3 (scores x 9: rows dominated by one or two keys, running maxima that jump
     by tens of units between key tiles -> the online-softmax rescale), one key that dominates EVERY row of head 1, and v with an
-    outlier column.  Against the fp64 reference of the same bf16 operands (P enters P.V as bf16): <= 1 ulp of the row maximum of
-    each head's 64-wide output (0.5 is the output rounding)."""
+    outlier column (x 40, inside the peaked head).  Against the fp64 reference of the same bf16 operands (P enters P.V as bf16).
+    The bound is the rounding the arithmetic is DEFINED to have, element by element: both sides round every probability to bf16 once
+    (the device relative to the running maximum of the key tile, the reference relative to the row maximum: two roundings of at most
+    2^-9 each, i.e. 2^-8 of the TERM p_j |v_jd|) and the device rounds its output to bf16 (2^-9 of the value).  Winner-take-all rows
+    over outlier values of both signs cancel, so an error bound in units of the OUTPUT would be unbounded; in units of the terms it
+    is tight (measured: 0.55 of the bound at most)."""
     from gitcap import _lib
     lib = _lib.load()
     W = H * 64
@@ -201,12 +205,18 @@ def test_attn_full_peaked_scores(G, S, H):
     q, k, v = (t.double().view(G, S, H, 64).transpose(1, 2) for t in qkv.split(W, dim=1))
     s = q @ k.transpose(-1, -2) * 0.125
     p = torch.exp(s - s.max(-1, keepdim=True).values)
-    ref = (p.bfloat16().double() @ v) / p.sum(-1, keepdim=True)
-    ref = ref.transpose(1, 2).reshape(G * S, H, 64)
-    e = ulps_of_rowmax(ctx.float().view(G * S, H, 64).cpu(), ref.cpu())
-    print(f"attn_full peaked G={G} S={S} H={H}: {e[0]:.3f} ulp of the (row, head) maximum, rms {e[1]:.4f}, largest {e[2]:.1f}")
+    l = p.sum(-1, keepdim=True)
+    ref = (p.bfloat16().double() @ v) / l
+    terms = (p @ v.abs()) / l                                                  # sum_j p_j |v_jd| / l: the magnitude the roundings act on
+    bound = 2.0 ** -8 * terms + 2.0 ** -9 * ref.abs() + 1e-6
+    got = ctx.double().view(G, S, H, 64).transpose(1, 2)
+    ratio = ((got - ref).abs() / bound)
+    e = ulps_of_rowmax(got.transpose(1, 2).reshape(G * S, H, 64).cpu(), ref.transpose(1, 2).reshape(G * S, H, 64).cpu())
+    print(f"attn_full peaked G={G} S={S} H={H}: max error / rounding bound {float(ratio.max()):.3f} (head 0: {float(ratio[:, 0].max()):.3f}, "
+          f"head 1: {float(ratio[:, 1].max()):.3f}); in ulps of the (row, head) maximum {e[0]:.2f} (rms {e[1]:.3f}), largest |ctx| {e[2]:.0f}")
     assert float(s[:, 0].amax(-1).mean()) > 20.0            # the scores really are peaked
-    assert e[0] < 1.0 and e[1] < 0.3
+    assert float(ratio.max()) < 1.0
+    assert e[1] < 0.3
 
 
 def test_text_rows_one_layer_peaked_head(captioner_cls):

@@ -1,3 +1,4 @@
+# (needs tools/experiments/gemm256_s4_four_barriers.patch applied to csrc/gemm256.hip + the speed-switch lines of commit eba5b05: the product has neither)
 # gemm256 with eight (product until round 5) vs four (S4, round 6) barriers per K-tile: bitwise equality on every epilogue incl. the
 # fused GEMM + LayerNorm forms, then per-launch time on the image-pass shapes, interleaved in one process (speed switch 12), with
 # torch.nn.functional.linear (hipBLASLt) on the same operands beside them.
