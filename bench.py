@@ -259,6 +259,43 @@ def other_configs(dev, note):
                          "decode_phase_ms": round(loop, 3), "decode_phase_hbm_frac": round(db / (loop * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     del m
     note("other_configs: configs[1] done")
+    # ---- configs[2] with the opt-in e4m3 V cache of the token loop (kv_cache="v_e4m3"; the headline stays bf16) ----
+    cfg = git_base(FRAMES)
+    w6 = synthetic_weights(cfg, seed=0)
+    ins6 = [torch.randn(CLIPS_PER_GPU, FRAMES, 3, cfg.image_size, cfg.image_size, generator=g).to(dev) for _ in range(2)]
+    rec = {}
+    for mode in ("bf16", "v_e4m3"):
+        m = GitCaptioner(cfg, w6, device=dev, max_batch=CLIPS_PER_GPU, max_frames=FRAMES, max_text_len=TOKENS, stop="never", kv_cache=mode)
+        kk = [0]
+
+        def one6():
+            kk[0] += 1
+            return m.greedy_decode(ins6[kk[0] % 2], max_len=TOKENS, stop="never")
+        ser = med_ms(one6)
+        t1 = med_ms(lambda: m.greedy_decode(ins6[0], max_len=1, stop="never"), n=5)
+        loop = (ser - t1) * TOKENS / (TOKENS - 1)
+
+        def pipe6(n):
+            pend = []
+            for i in range(n):
+                pend.append(m.greedy_decode_async(ins6[i % 2], max_len=TOKENS, stop="never"))
+                if len(pend) == 3:
+                    pend.pop(0).result()
+            while pend:
+                pend.pop(0).result()
+        pipe6(4)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        pipe6(18)
+        torch.cuda.synchronize(dev)
+        pp = (time.perf_counter() - t0) / 18 * 1e3
+        rec[mode] = {"serial_ms_per_batch": round(ser, 3), "decode_phase_ms": round(loop, 3), "image_pass_ms": round(t1 - loop / TOKENS, 3),
+                     "pipelined_ms_per_batch": round(pp, 3), "pipelined_captions_per_s": round(CLIPS_PER_GPU * 1e3 / pp, 1),
+                     "workspace_mbytes": round(m.workspace_bytes() / 1e6, 1)}
+        del m
+    out["kv_cache_v_e4m3"] = {"workload": "BASELINE configs[2] (16 x 6-frame clips, GIT-base, 20 greedy tokens) with the image prefix's V rows as "
+                              "e4m3 codes for the token loop (opt-in; results differ by the rounding of V), beside the default on the same box", **rec}
+    note("other_configs: kv_cache v_e4m3 done")
     # ---- the webcam shape: one clip, CPU in / CPU out, 25 tokens (real_time_inference.py:56-58) ----
     cfg = git_base(FRAMES)
     m = GitCaptioner(cfg, synthetic_weights(cfg, seed=0), device=dev, max_batch=1, max_frames=FRAMES, max_text_len=25, stop="never")

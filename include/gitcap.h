@@ -112,6 +112,19 @@ int gitcap_set_fp8_scale(gitcap_t* h, float scale);
 int gitcap_fp8_saturations(gitcap_t* h, int64_t* count, int reset);
 int gitcap_weight_bytes(const gitcap_t* h, int64_t* bytes);
 
+/* Format of the image-prefix V rows the TOKEN LOOP reads (north_star: "a KV cache for the decode loop ... bf16/fp8"; the reference
+ * has no cache at all, src/models/model.py:412-418 recomputes the prefix for every token).  GITCAP_KV_BF16 (default): the q|k|v
+ * GEMM output of the decoder's image rows as it is.  GITCAP_KV_V_E4M3 (opt-in): a second copy of the V rows as OCP e4m3 codes with
+ * one power-of-two scale per (token, head), written once per clip behind each decoder layer's q|k|v GEMM; the text rows' attention
+ * reads K in bf16 and V from the codes (3/4 of the bytes of its K/V stream).  K stays bf16 in every mode: a peaked head's scores do
+ * not survive a 6 % step on a key (profiles/r05_fp8_kv_cache_study.txt: up to 2.5 on logits of std 4).  The image rows' own
+ * attention, the text rows' own K/V and all arithmetic are unchanged; results differ from the default by the rounding of V
+ * (measured |dlogit| 0.10 plain / 0.5 stress weights); the oracle's counterpart is GitOracle(emulate_fp8_v=True).  The exact
+ * KV-cache property (cached step == teacher-forced pass, bitwise) and batch invariance hold in either mode.  Synchronises the device;
+ * +3/8 of the image K/V bytes of workspace (4 slots). */
+enum { GITCAP_KV_BF16 = 0, GITCAP_KV_V_E4M3 = 1 };
+int gitcap_set_kv_cache(gitcap_t* h, int mode);
+
 /* Replaces: self.image_encoder(torch.stack(batch['image'])) + temporal add + cat(dim=1)
  *                                                         src/models/model.py:378-382
  *           the 'linearLn' visual projection              src/models/model.py:699

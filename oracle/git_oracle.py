@@ -64,7 +64,8 @@ FP8_FFN_SCALE = 1.0 / 16.0      # default static scale of the e4m3 FFN activatio
 
 class GitOracle:
     def __init__(self, cfg, weights: Dict[str, np.ndarray], emulate_bf16: bool = False,
-                 threads: Optional[int] = None, emulate_fp8_act: bool = False, fp8_scale: float = FP8_FFN_SCALE):
+                 threads: Optional[int] = None, emulate_fp8_act: bool = False, fp8_scale: float = FP8_FFN_SCALE,
+                 emulate_fp8_v: bool = False):
         self.cfg = cfg
         self.bf = bool(emulate_bf16)
         # True (study, oracle/fp8_act_study.py): the activation operand of every image-row GEMM (not the patch embedding, not
@@ -74,6 +75,10 @@ class GitOracle:
         self.f8 = emulate_fp8_act if emulate_fp8_act == "ffn" else bool(emulate_fp8_act)
         self.f8_scale = float(fp8_scale)   # "ffn" mode: the device's gitcap_set_fp8_scale
         self.f8_sat = 0                    # "ffn" mode: codes clamped at +-448 so far (the device's gitcap_fp8_saturations)
+        # The device's opt-in kv_cache="v_e4m3": the TEXT rows' attention reads the V rows of the IMAGE keys as e4m3 codes with one
+        # power-of-two scale per (token, head) (csrc/rowops.hip: kv_quant_v_kernel); K, the text rows' own K/V and the image rows'
+        # own attention stay bf16.
+        self.f8v = bool(emulate_fp8_v)
         if threads:
             torch.set_num_threads(threads)
         self.w: Dict[str, torch.Tensor] = {}
@@ -217,6 +222,17 @@ class GitOracle:
         k, v = self._kv(i, x, True)
         return self._dec_layer(i, x, k, v, torch.full((S_img,), S_img), True)
 
+    def _vq(self, v: torch.Tensor) -> torch.Tensor:
+        """Image-prefix V [B,H,S,64] as the text attention sees it (identity unless emulate_fp8_v)."""
+        return _q8(v) if self.f8v else v
+
+    def dec_layer_text(self, i: int, x: torch.Tensor, S_img: int) -> torch.Tensor:
+        """The TEXT rows of one decoder layer over [image ; text] rows x [B, S_img + T, D] (image keys' V through _vq): [B, T, D]."""
+        T = x.shape[1] - S_img
+        k, v = self._kv(i, x)
+        v = torch.cat([self._vq(v[:, :, :S_img]), v[:, :, S_img:]], dim=2)
+        return self._dec_layer(i, x[:, S_img:], k, v, S_img + torch.arange(T) + 1)
+
     def decoder_full(self, memory: torch.Tensor, ids: torch.Tensor,
                      return_hidden: bool = False):
         """Full (no-cache) pass over [image ; text] with the GIT block mask:
@@ -225,6 +241,9 @@ class GitOracle:
         features [B,S_img,D]; ids [B,T].  Returns logits [B,T,V]."""
         cfg = self.cfg
         S_img, T = memory.shape[1], ids.shape[1]
+        if self.f8v:                  # the text rows see a different V of the image keys than the image rows do: the split form
+            assert not return_hidden
+            return self.decoder_text(self.image_kv(memory), ids)
         x = torch.cat([memory, self.embed_text(ids)], dim=1)
         rows = torch.arange(S_img + T)
         klimit = torch.where(rows < S_img, torch.full_like(rows, S_img), rows + 1)
@@ -246,7 +265,7 @@ class GitOracle:
         full = torch.full((S_img,), S_img)
         for i in range(cfg.dec_layers):
             k, v = self._kv(i, x, True)
-            kv.append((k, v))
+            kv.append((k, self._vq(v)))             # what the TEXT rows read; the image rows' own attention below keeps bf16 V
             if i + 1 < cfg.dec_layers:
                 x = self._dec_layer(i, x, k, v, full, True)
         return kv
@@ -271,6 +290,16 @@ class GitOracle:
     def prefill(self, memory: torch.Tensor, ids: torch.Tensor):
         cfg = self.cfg
         S_img, T = memory.shape[1], ids.shape[1]
+        if self.f8v:                  # image half once (its V quantised for the text rows), then the text prefix against it
+            ikv = self.image_kv(memory)
+            x = self.embed_text(ids)
+            cache = []
+            for i in range(cfg.dec_layers):
+                kt, vt = self._kv(i, x)
+                k, v = torch.cat([ikv[i][0], kt], dim=2), torch.cat([ikv[i][1], vt], dim=2)
+                cache.append([k, v])
+                x = self._dec_layer(i, x, k, v, S_img + torch.arange(T) + 1)
+            return self._lin(x[:, -1], "head"), cache, T
         x = torch.cat([memory, self.embed_text(ids)], dim=1)
         rows = torch.arange(S_img + T)
         klimit = torch.where(rows < S_img, torch.full_like(rows, S_img), rows + 1)

@@ -111,6 +111,10 @@ struct gitcap {
     unsigned long long* f8_sat = nullptr;            // device counter: codes of valid rows the producing epilogues clamped at +-448
     unsigned char *hb8 = nullptr, *ffn8 = nullptr;   // [Mi][Dm] LayerNorm output / [Mi][Fm] GELU output as e4m3 codes of value * 16
     bf16_t *hb = nullptr, *qkv = nullptr, *ctx = nullptr, *ffn = nullptr, *patches = nullptr, *kv_img = nullptr;
+    // opt-in kv_cache = v_e4m3 (gitcap_set_kv_cache): V of the image prefix as e4m3 codes [layer][Mi][D] + power-of-two scales
+    // [layer][Mi][H] per (token, head), written behind every decoder layer's q|k|v GEMM of the image rows, read by txt_block
+    bool kv_v8 = false;
+    unsigned char* v8_img = nullptr; float* vs_img = nullptr;       // views into the selected slot
     // workspace (text rows)
     float *xs = nullptr, *xs2 = nullptr, *slabs = nullptr, *part = nullptr, *amax_val = nullptr;
     int* amax_idx = nullptr;
@@ -143,6 +147,7 @@ struct gitcap {
     // stream; they first make that stream wait for every submission still in flight (join_async).
     struct Slot {
         bf16_t* kv_img = nullptr; int32_t* sep_cnt = nullptr;
+        unsigned char* v8_img = nullptr; float* vs_img = nullptr;   // kv_cache = v_e4m3
         // text-row workspace of the slot (token loops of different slots may run concurrently)
         float *xs = nullptr, *xs2 = nullptr, *slabs = nullptr, *part = nullptr, *amax_val = nullptr; int* amax_idx = nullptr;
         unsigned* row_cnt = nullptr;
@@ -208,6 +213,7 @@ void select_slot(gitcap* h, int i) {
     o.kv_txt = h->kv_txt; o.kv_txt2 = h->kv_txt2;        // reorder_rows swaps these two
     gitcap::Slot& n = h->slots[i];
     h->kv_img = n.kv_img; h->sep_cnt = n.sep_cnt; h->cur_B = n.B; h->cur_S = n.S; h->have_image = n.have;
+    h->v8_img = n.v8_img; h->vs_img = n.vs_img;
     h->xs = n.xs; h->xs2 = n.xs2; h->slabs = n.slabs; h->part = n.part; h->row_cnt = n.row_cnt; h->amax_val = n.amax_val; h->amax_idx = n.amax_idx;
     h->xsb = n.xsb; h->fs = n.fs; h->kv_txt = n.kv_txt; h->kv_txt2 = n.kv_txt2;
     h->beam = n.beam; h->beam_logits = n.beam_logits; h->cand_scores = n.cand_scores; h->cand_idx = n.cand_idx; h->topk_scratch = n.topk_scratch;
@@ -488,6 +494,13 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
         return hid ? hipMemcpyAsync(h->hid_img + (size_t)entry * h->Mi * D, h->x, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, s) : hipSuccess;
     };
     HIP_OK(h, keep(0));
+    // kv_cache = v_e4m3: the text attention's copy of this layer's V rows (codes + scales); the image rows' own attention keeps bf16
+    auto quant_v = [&](int l, const bf16_t* kv) -> int {
+        if (!h->kv_v8) return 0;
+        ProfScope ps(h, GITCAP_PROF_ROWOPS, s, 0.0, (double)rows * D * 3.0);
+        HIP_OK(h, launch_kv_quant_v(kv, h->v8_img + (size_t)l * h->Mi * D, h->vs_img + (size_t)l * h->Mi * c.dec_heads, rows, D, c.dec_heads, s));
+        return 0;
+    };
     for (int l = 0; l < c.dec_layers; ++l) {
         const DecLayer& L = h->dec[l];
         bf16_t* kv = h->kv_img + (size_t)l * kv_layer;
@@ -498,6 +511,7 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
                 if ((rc = stage_layer(h, s, ws, wr, wk, f8 ? 2 : 4))) return rc;
             }
             if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, D, L.qkvw, L.qkvb, rows, Mp, 3 * D, D, kv, 3 * D))) return rc;
+            if ((rc = quant_v(l, kv))) return rc;
             {
                 ProfScope ps(h, GITCAP_PROF_ATTN_FULL, s, 4.0 * B * c.dec_heads * (double)S * S * 64, 0.0);
                 HIP_OK(h, launch_attn_full(kv, h->ctx, B, S, c.dec_heads, s));
@@ -513,6 +527,7 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
         } else {
             // last layer: image rows are only ever read as keys/values -> K,V projections only
             if ((rc = gemm(h, s, EPI_BIAS_BF16, h->hb, D, L.qkvw.rows_from(D, D), L.qkvb + D, rows, Mp, 2 * D, D, kv + D, 3 * D))) return rc;
+            if ((rc = quant_v(l, kv))) return rc;
         }
     }
     h->cur_B = B; h->cur_S = S; h->have_image = true;
@@ -602,12 +617,14 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
             ta.rows = rows; ta.beams = beams; ta.t0 = t0; ta.T = T; ta.Tmax = h->Tmax; ta.S_img = h->cur_S; ta.H = H; ta.D = D;
             ta.aow = L.aow.p; ta.aowpk = L.aow.scale ? nullptr : L.aow.pk; ta.aoscale = L.aow.scale; ta.aob = L.aob; ta.g1 = L.ln1w; ta.b1 = L.ln1b; ta.xin = xcur; ta.eps = c.dec_ln_eps;
             ta.part = h->part; ta.cnt = h->row_cnt; ta.xs = xcur; ta.xsb = h->xsb;
+            if (h->kv_v8) { ta.v8_img = h->v8_img + (size_t)l * h->Mi * D; ta.vs_img = h->vs_img + (size_t)l * h->Mi * H; }
             // K/V of all layers that one token step streams: beyond what the 256 MiB Infinity Cache can keep next to the
             // 132 MB of decoder weights, the rows are loaded non-temporally (16 clips x 6 frames: 349 MB per step; measured
             // +0.6 % pipelined, -1 % serial step; one clip stays cached across steps and is 4 % faster with the default policy)
             ta.nt_kv = (double)h->cur_B * c.dec_layers * 2.0 * h->cur_S * D * 2.0 > 128e6 ? 1 : 0;
             double kvb = 0;
             for (int j = 0; j < T; ++j) kvb += (double)rows * (h->cur_S + t0 + j + 1) * 2 * D * 2;
+            if (h->kv_v8) kvb -= (double)rows * T * h->cur_S * (D - 4.0 * H);          // image V: 1 byte per element + 4 per (key, head)
             ProfScope ps(h, GITCAP_PROF_ATTN_TEXT, s, 0.0, kvb + (L.aow.scale ? 1.0 : 2.0) * D * D);     // K/V read once + the output dense
             HIP_OK(h, launch_txt_block(ta, s));
         }
@@ -1604,6 +1621,26 @@ int gitcap_set_weight_storage(gitcap_t* h, int storage) {
     for (auto& kv : h->w)
         if (kv.second.loaded && kv.second.bf16) return fail(h, GITCAP_ERR_STATE, "set_weight_storage: call it before the first gitcap_load_tensor");
     h->fp8 = storage == GITCAP_W_FP8_E4M3;
+    return 0;
+}
+
+int gitcap_set_kv_cache(gitcap_t* h, int mode) {
+    if (!h) return fail(h, GITCAP_ERR_ARG, "set_kv_cache: null handle");
+    if (mode != GITCAP_KV_BF16 && mode != GITCAP_KV_V_E4M3) return fail(h, GITCAP_ERR_ARG, "set_kv_cache: unknown mode");
+    GUARD(h);
+    HIP_OK(h, hipDeviceSynchronize());          // not between the launches of a submission in flight
+    select_slot(h, 0);
+    if (mode == GITCAP_KV_V_E4M3 && !h->slots[0].v8_img) {
+        for (auto& sl : h->slots) {
+            int rc = ws_alloc(h, &sl.v8_img, (size_t)h->c.dec_layers * h->Mi * h->D);
+            rc = rc ? rc : ws_alloc(h, &sl.vs_img, (size_t)h->c.dec_layers * h->Mi * h->c.dec_heads);
+            if (rc) return rc;
+        }
+        h->v8_img = h->slots[0].v8_img; h->vs_img = h->slots[0].vs_img;
+    }
+    h->kv_v8 = mode == GITCAP_KV_V_E4M3;
+    h->have_image = false;
+    for (auto& sl : h->slots) sl.have = false;
     return 0;
 }
 

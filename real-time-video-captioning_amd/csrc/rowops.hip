@@ -752,6 +752,51 @@ hipError_t launch_im2col(const float* frames, bf16_t* patches, int nf, int img, 
 
 
 
+// ---- V of the image prefix as OCP e4m3 codes + one power-of-two scale per (token, head) (opt-in kv_cache = v_e4m3) -------
+// kv: [rows][3D] bf16 (q | k | v of one decoder layer's image rows) -> v8 [rows][D] codes, vs [rows][H] scales.  Eight lanes per
+// (row, head): 8 values each; scale = the smallest 2^e with amax <= 448 * 2^e (exact: amax / 2^(E-8) lies in [256, 512), compared
+// with 448 after an exact scaling), codes round to nearest even; code * scale is a bf16 value.
+namespace {
+__global__ __launch_bounds__(256) void kv_quant_v_kernel(const bf16_t* __restrict__ kv, unsigned char* __restrict__ v8, float* __restrict__ vs,
+                                                         int64_t groups, int D, int H) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t gi = t >> 3;
+    const int sub = (int)(t & 7);
+    const bool live = gi < groups;
+    const int64_t g = live ? gi : groups - 1;
+    const int64_t row = g / H;
+    const int head = (int)(g - row * H);
+    const bf16x8 x = *(const bf16x8*)(kv + row * 3 * D + 2 * D + head * 64 + sub * 8);
+    float f[8], amax = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { f[d] = bf2f((bf16_t)x[d]); amax = fmaxf(amax, fabsf(f[d])); }
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    amax = fmaxf(amax, __shfl_xor(amax, 4));
+    float scale = 1.0f;
+    if (amax > 0.f) {
+        const int E = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127;          // floor(log2 amax) (bf16 values: never denormal in fp32)
+        scale = __uint_as_float((unsigned)(E - 8 + 127) << 23);                    // amax / scale in [256, 512)
+        if (amax > 448.0f * scale) scale *= 2.0f;
+    }
+    const float inv = 1.0f / scale;                                                // a power of two: exact
+    uint2 q;
+    q.x = pack_fp8x4(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv);
+    q.y = pack_fp8x4(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv);
+    if (live) {
+        *(uint2*)(v8 + row * D + head * 64 + sub * 8) = q;
+        if (sub == 0) vs[row * H + head] = scale;
+    }
+}
+}  // namespace
+
+hipError_t launch_kv_quant_v(const bf16_t* kv, unsigned char* v8, float* vs, int rows, int D, int H, hipStream_t s) {
+    if (rows <= 0 || H * 64 != D) return hipErrorInvalidValue;
+    const int64_t groups = (int64_t)rows * H;
+    hipLaunchKernelGGL(kv_quant_v_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, s, kv, v8, vs, groups, D, H);
+    return hipGetLastError();
+}
+
 hipError_t launch_cast_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s) {
     if (n % 4) return hipErrorInvalidValue;
     const int64_t n4 = n / 4;

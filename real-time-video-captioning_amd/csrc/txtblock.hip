@@ -110,7 +110,13 @@ __device__ __forceinline__ void block_layernorm(float (&v)[NC], const bool (&act
 // of K/V each, two rounds of 16-wave workgroups.  The keys are dealt to 16 VIRTUAL waves either way (virtual wave v takes
 // the 32-key groups v, v + 16, ...; a physical wave of the 8-wave form runs virtual waves wid and wid + 8 one after the
 // other) and every merge is in virtual-wave order, so both forms give the same bits (speed switch 9 / tests).
-template <int K32, bool FP8, int NW, bool NT_KV>
+// V8 (opt-in kv_cache = v_e4m3): the V rows of the IMAGE keys come as e4m3 codes + one power-of-two scale per (key, head)
+// (rowops.hip: kv_quant_v_kernel; 3/4 of the bytes of the K/V stream), K and the row's own text K/V stay bf16.  The image keys are
+// dealt to the 16 virtual waves in 32-key groups as before; the text keys 0..t of the row (a second format) are one more run of
+// groups handled by the virtual wave that is next in the dealing, tw = ceil(S_img / 32) mod 16, after its image groups and into the
+// same softmax state.  The summation order is a function of (S_img, t) only: batch invariant, cached == teacher-forced bitwise.
+// p * (code * scale) is computed as (p * scale) * code: the same real product, rounded once by the same FMA.
+template <int K32, bool FP8, int NW, bool NT_KV, bool V8 = false>
 __global__ __launch_bounds__(NW * 64, 4) void txt_block_kernel(TxtBlockArgs a) {
     constexpr int D = K32 * 32;
     constexpr int NC = 16 / NW;                                 // columns (virtual waves) per thread in the row reducer
@@ -232,6 +238,118 @@ __global__ __launch_bounds__(NW * 64, 4) void txt_block_kernel(TxtBlockArgs a) {
             for (int d = 0; d < 8; ++d) wsm[vw][sub][2 + d] = st.o[d];
         }
     };
+    if constexpr (V8) {
+        const int S = a.S_img;
+        const unsigned char* v8p = a.v8_img + (size_t)clip * S * D + head * 64 + sub * 8;
+        const float* vsp = a.vs_img + (size_t)clip * S * H + head;
+        typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+        struct G8 { bf16x8 k[4]; u32x2 v[4]; float sc[4]; bool ok[4]; };
+        auto load8 = [&](int g0, G8& x) {                                  // image keys g0 .. g0 + 31 (past the last: key 0, masked)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int key = g0 + u * 8 + kk;
+                x.ok[u] = key < S;
+                key = x.ok[u] ? key : 0;
+                const bf16_t* kp = img + (size_t)key * ld;
+                const u32x2* vp = (const u32x2*)(v8p + (size_t)key * D);
+                const float* sp = vsp + (size_t)key * H;
+                x.k[u] = NT_KV ? __builtin_nontemporal_load((const bf16x8*)kp) : *(const bf16x8*)kp;
+                x.v[u] = NT_KV ? __builtin_nontemporal_load(vp) : *vp;
+                x.sc[u] = NT_KV ? __builtin_nontemporal_load(sp) : *sp;
+            }
+        };
+        auto reduce8 = [&](const G8& x) {
+#pragma clang fp contract(off)
+            float sc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) s = __builtin_fmaf(qv[d], bf2f((bf16_t)x.k[u][d]), s);
+                s += __shfl_xor(s, 1);
+                s += __shfl_xor(s, 2);
+                s += __shfl_xor(s, 4);
+                sc[u] = x.ok[u] ? s : -INFINITY;
+            }
+            const float mt = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+            const float m_new = fmaxf(st.m, mt);
+            if (m_new != -INFINITY) {
+                const float alpha = (st.m == -INFINITY) ? 0.f : ex2(st.m - m_new);
+                st.l *= alpha;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) st.o[d] *= alpha;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float p = ex2(sc[u] - m_new);             // exp2(-inf) = 0 for masked keys
+                    st.l += p;
+                    const float pbs = bf2f(f2bf(p)) * x.sc[u];      // P enters the PV product as bf16; x the key's power-of-two scale: exact
+                    typedef __attribute__((ext_vector_type(2))) float f32x2;
+                    const f32x2 c01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)x.v[u][0], false), c23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)x.v[u][0], true);
+                    const f32x2 c45 = __builtin_amdgcn_cvt_pk_f32_fp8((int)x.v[u][1], false), c67 = __builtin_amdgcn_cvt_pk_f32_fp8((int)x.v[u][1], true);
+                    const float c[8] = {c01[0], c01[1], c23[0], c23[1], c45[0], c45[1], c67[0], c67[1]};
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) st.o[d] = __builtin_fmaf(pbs, c[d], st.o[d]);
+                }
+                st.m = m_new;
+            }
+        };
+        const int tw = ((S + 31) >> 5) & 15;                               // the virtual wave that also takes the row's text keys
+        bf16x8 kT[4], vT[4];
+        bool okT[4];
+        auto text_keys = [&]() {                                           // keys S .. Lk - 1, bf16, 32 at a time (loads and reduces in one branch)
+            for (int tg = S; tg < Lk; tg += 32) {
+                load_group(tg, kT, vT, okT);
+                reduce_group(kT, vT, okT);
+            }
+        };
+        G8 A, B;
+        if (NW == 16) {
+            int g = wid * 32;
+            if (g < S) {
+                load8(g, A);
+                load8(g + 512, B);
+                convert_q();
+                reduce8(A);
+                load8(g + 1024, A);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 512 < S) reduce8(B);
+                load8(g + 1536, B);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1024 < S) reduce8(A);
+                g += 1536;
+                while (g < S) {                                            // longer prefixes: B holds group g
+                    load8(g + 512, A);
+                    reduce8(B);
+                    g += 512;
+                    if (g >= S) break;
+                    load8(g + 512, B);
+                    reduce8(A);
+                    g += 512;
+                }
+            } else {
+                convert_q();
+            }
+            if (wid == tw) text_keys();
+            finish_virtual(wid);
+        } else {
+            convert_q();
+            for (int g = wid * 32; g < S; g += 512) {
+                load8(g, A);
+                reduce8(A);
+            }
+            if (wid == tw) text_keys();
+            finish_virtual(wid);
+            st.m = -INFINITY; st.l = 0.f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) st.o[d] = 0.f;
+            for (int g = (wid + 8) * 32; g < S; g += 512) {
+                load8(g, A);
+                reduce8(A);
+            }
+            if (wid + 8 == tw) text_keys();
+            finish_virtual(wid + 8);
+        }
+    } else
     {
         bf16x8 kA[4], vA[4], kB[4], vB[4];
         bool okA[4], okB[4];
@@ -420,18 +538,19 @@ hipError_t launch_txt_block(const TxtBlockArgs& a_in, hipStream_t s) {
     static const int nt = getenv("GITCAP_TXT_NT") ? atoi(getenv("GITCAP_TXT_NT")) : -1;    // A/B switch: 0 never, 1 always
     if (nt >= 0) a.nt_kv = nt;
     const int M = a.rows * a.T;
-    if (M <= 0 || a.H * 64 != a.D || a.beams <= 0 || !a.xin) return hipErrorInvalidValue;
+    if (M <= 0 || a.H * 64 != a.D || a.beams <= 0 || !a.xin || (a.v8_img != nullptr) != (a.vs_img != nullptr)) return hipErrorInvalidValue;
     // first "half" of the rows for heads 8..11 (H == 12 mapping): whole clips (all beams of a clip stay together)
     const int unit = a.T == 1 ? a.beams : 1;
     a.Mh = ((M / unit + 1) / 2) * unit;
     const int grid = a.H == 12 ? 8 * (M + (a.Mh > M - a.Mh ? a.Mh : M - a.Mh)) : M * a.H;
     const bool w8 = g_txt8 && M * a.H > device_cus();
     const int key = a.D * 2 + (a.aoscale ? 1 : 0);
-#define TXT_LAUNCH(K32, F8) do { \
-        if (w8) { if (a.nt_kv) hipLaunchKernelGGL((txt_block_kernel<K32, F8, 8, true>), dim3(grid), dim3(512), 0, s, a); \
-                  else hipLaunchKernelGGL((txt_block_kernel<K32, F8, 8, false>), dim3(grid), dim3(512), 0, s, a); } \
-        else { if (a.nt_kv) hipLaunchKernelGGL((txt_block_kernel<K32, F8, 16, true>), dim3(grid), dim3(1024), 0, s, a); \
-               else hipLaunchKernelGGL((txt_block_kernel<K32, F8, 16, false>), dim3(grid), dim3(1024), 0, s, a); } } while (0)
+#define TXT_LAUNCH_V(K32, F8, V8) do { \
+        if (w8) { if (a.nt_kv) hipLaunchKernelGGL((txt_block_kernel<K32, F8, 8, true, V8>), dim3(grid), dim3(512), 0, s, a); \
+                  else hipLaunchKernelGGL((txt_block_kernel<K32, F8, 8, false, V8>), dim3(grid), dim3(512), 0, s, a); } \
+        else { if (a.nt_kv) hipLaunchKernelGGL((txt_block_kernel<K32, F8, 16, true, V8>), dim3(grid), dim3(1024), 0, s, a); \
+               else hipLaunchKernelGGL((txt_block_kernel<K32, F8, 16, false, V8>), dim3(grid), dim3(1024), 0, s, a); } } while (0)
+#define TXT_LAUNCH(K32, F8) do { if (a.v8_img) TXT_LAUNCH_V(K32, F8, true); else TXT_LAUNCH_V(K32, F8, false); } while (0)
     switch (key) {
         case 256: TXT_LAUNCH(4, false); break;
         case 257: TXT_LAUNCH(4, true); break;
@@ -440,5 +559,6 @@ hipError_t launch_txt_block(const TxtBlockArgs& a_in, hipStream_t s) {
         default: return hipErrorInvalidValue;
     }
 #undef TXT_LAUNCH
+#undef TXT_LAUNCH_V
     return hipGetLastError();
 }

@@ -24,6 +24,7 @@ SYMBOLS = {
     "gitcap_hidden_states_read": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "gitcap_set_weight_storage": (c_int, [c_void_p, c_int]),
     "gitcap_set_compute": (c_int, [c_void_p, c_int]),
+    "gitcap_set_kv_cache": (c_int, [c_void_p, c_int]),
     "gitcap_set_fp8_scale": (c_int, [c_void_p, c_float]),
     "gitcap_fp8_saturations": (c_int, [c_void_p, POINTER(c_int64), c_int]),
     "gitcap_weight_bytes": (c_int, [c_void_p, POINTER(c_int64)]),

@@ -254,7 +254,7 @@ class GitCaptioner(nn.Module):
     def __init__(self, cfg: Optional[GitCapConfig] = None, weights: Optional[Mapping[str, np.ndarray]] = None, *,
                  device: str | torch.device = "cuda:0", max_batch: int = 16, max_frames: Optional[int] = None,
                  max_text_len: int = 32, max_beams: int = 1, tokenizer=None, stop: str = "all_sep",
-                 weight_dtype: str = "bf16", compute: str = "bf16", fp8_scale: Optional[float] = None,
+                 weight_dtype: str = "bf16", compute: str = "bf16", fp8_scale: Optional[float] = None, kv_cache: str = "bf16",
                  # constructor kwargs of the reference student (model.py:55-57); only the ids/vocab matter here
                  vocab_length: Optional[int] = None, cls_token_id: Optional[int] = None,
                  sep_token_id: Optional[int] = None, **_ignored_student_kwargs):
@@ -285,8 +285,11 @@ class GitCaptioner(nn.Module):
         if fp8_scale is not None and compute != "fp8_ffn":
             raise ValueError("fp8_scale is the activation scale of compute='fp8_ffn'")
         self.fp8_scale = None if fp8_scale is None else float(fp8_scale)
-        self._kw = dict(max_batch=max_batch, max_frames=max_frames, max_text_len=max_text_len,
-                        max_beams=max_beams, stop=stop, weight_dtype=weight_dtype, compute=compute, fp8_scale=fp8_scale)
+        if kv_cache not in ("bf16", "v_e4m3"):
+            raise ValueError("kv_cache must be 'bf16' or 'v_e4m3' (the token loop reads the image prefix's V rows as e4m3 codes)")
+        self.kv_cache = kv_cache
+        self._kw = dict(max_batch=max_batch, max_frames=max_frames, max_text_len=max_text_len, max_beams=max_beams, stop=stop,
+                        weight_dtype=weight_dtype, compute=compute, fp8_scale=fp8_scale, kv_cache=kv_cache)
         self._dev = torch.device(device)
         self._handle = None
         self._weights: Optional[Dict[str, np.ndarray]] = None
@@ -325,6 +328,8 @@ class GitCaptioner(nn.Module):
             self._call("gitcap_set_compute", 1)
             if self.fp8_scale is not None:
                 self._call("gitcap_set_fp8_scale", ctypes.c_float(self.fp8_scale))
+        if self.kv_cache == "v_e4m3":           # image-prefix V as e4m3 codes for the token loop (include/gitcap.h: gitcap_set_kv_cache)
+            self._call("gitcap_set_kv_cache", 1)
 
     def __del__(self):
         try:
