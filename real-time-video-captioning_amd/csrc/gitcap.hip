@@ -498,7 +498,7 @@ int image_prefix(gitcap* h, int B, int S, hipStream_t s) {
     auto quant_v = [&](int l, const bf16_t* kv) -> int {
         if (!h->kv_v8) return 0;
         ProfScope ps(h, GITCAP_PROF_ROWOPS, s, 0.0, (double)rows * D * 3.0);
-        HIP_OK(h, launch_kv_quant_v(kv, h->v8_img + (size_t)l * h->Mi * D, h->vs_img + (size_t)l * h->Mi * c.dec_heads, rows, D, c.dec_heads, s));
+        HIP_OK(h, launch_kv_quant_v(kv, h->v8_img + (size_t)l * h->Mi * D, h->vs_img + (size_t)l * h->Mi * c.dec_heads, rows, D, c.dec_heads, h->Mi, s));
         return 0;
     };
     for (int l = 0; l < c.dec_layers; ++l) {
@@ -617,7 +617,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
             ta.rows = rows; ta.beams = beams; ta.t0 = t0; ta.T = T; ta.Tmax = h->Tmax; ta.S_img = h->cur_S; ta.H = H; ta.D = D;
             ta.aow = L.aow.p; ta.aowpk = L.aow.scale ? nullptr : L.aow.pk; ta.aoscale = L.aow.scale; ta.aob = L.aob; ta.g1 = L.ln1w; ta.b1 = L.ln1b; ta.xin = xcur; ta.eps = c.dec_ln_eps;
             ta.part = h->part; ta.cnt = h->row_cnt; ta.xs = xcur; ta.xsb = h->xsb;
-            if (h->kv_v8) { ta.v8_img = h->v8_img + (size_t)l * h->Mi * D; ta.vs_img = h->vs_img + (size_t)l * h->Mi * H; }
+            if (h->kv_v8) { ta.v8_img = h->v8_img + (size_t)l * h->Mi * D; ta.vs_img = h->vs_img + (size_t)l * h->Mi * H; ta.v8_pitch = h->Mi; }
             // K/V of all layers that one token step streams: beyond what the 256 MiB Infinity Cache can keep next to the
             // 132 MB of decoder weights, the rows are loaded non-temporally (16 clips x 6 frames: 349 MB per step; measured
             // +0.6 % pipelined, -1 % serial step; one clip stays cached across steps and is 4 % faster with the default policy)

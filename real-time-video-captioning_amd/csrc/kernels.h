@@ -158,9 +158,9 @@ struct TxtBlockArgs {
     float* part;                                // [M][H][D] fp32 per-head partials of the output dense
     unsigned* cnt;                              // [M] arrival tickets (zero between launches)
     float* xs; bf16_t* xsb;                     // out: x1 [M][D] fp32 and bf16 (xs may alias xin)
-    // opt-in kv_cache = v_e4m3: V of the image keys as e4m3 codes [B*S_img][D] + one power-of-two scale per (key, head)
-    // [B*S_img][H] (launch_kv_quant_v); K and the text rows' own K/V stay bf16.  nullptr: bf16 V from kv_img.
-    const unsigned char* v8_img; const float* vs_img;
+    // opt-in kv_cache = v_e4m3: V of the image keys as e4m3 codes [H][v8_pitch][64] + one power-of-two scale per (key, head)
+    // [H][v8_pitch], head-major (launch_kv_quant_v); K and the text rows' own K/V stay bf16.  nullptr: bf16 V from kv_img.
+    const unsigned char* v8_img; const float* vs_img; int64_t v8_pitch;
     int Mh;                                     // set by the launcher
     int nt_kv;                                  // 1: the K/V rows are streamed with non-temporal loads (they do not fit the caches anyway)
 };
@@ -208,8 +208,8 @@ hipError_t launch_im2col(const float* frames, bf16_t* patches, int nf, int img, 
 // out[b][e][s][:] = s < S_img ? img[e][b*S_img + s][:] : txt[e][b*T + s - S_img][:]   (e < n_entries; fp32 rows of D)
 hipError_t launch_gather_hidden(const float* img, const float* txt, float* out, int n_entries, int B, int S_img, int T, int D,
                                 size_t img_entry_stride, size_t txt_entry_stride, hipStream_t s);
-// V slice of kv [rows][3D] (bf16) -> e4m3 codes v8 [rows][D] + power-of-two scales vs [rows][H] per (row, head)
-hipError_t launch_kv_quant_v(const bf16_t* kv, unsigned char* v8, float* vs, int rows, int D, int H, hipStream_t s);
+// V slice of kv [rows][3D] (bf16) -> e4m3 codes v8 [H][pitch][64] + power-of-two scales vs [H][pitch] per (row, head), head-major
+hipError_t launch_kv_quant_v(const bf16_t* kv, unsigned char* v8, float* vs, int rows, int D, int H, int64_t pitch, hipStream_t s);
 // f32 -> bf16 copy
 hipError_t launch_cast_bf16(const float* in, bf16_t* out, int64_t n, hipStream_t s);
 // e4m3 weight rows [rows][K] (+ per-row power-of-two scale) -> bf16 [rows][K] (exact); K % 16 == 0

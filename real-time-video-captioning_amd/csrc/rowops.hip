@@ -753,12 +753,13 @@ hipError_t launch_im2col(const float* frames, bf16_t* patches, int nf, int img, 
 
 
 // ---- V of the image prefix as OCP e4m3 codes + one power-of-two scale per (token, head) (opt-in kv_cache = v_e4m3) -------
-// kv: [rows][3D] bf16 (q | k | v of one decoder layer's image rows) -> v8 [rows][D] codes, vs [rows][H] scales.  Eight lanes per
+// kv: [rows][3D] bf16 (q | k | v of one decoder layer's image rows) -> v8 [H][pitch][64] codes, vs [H][pitch] scales, HEAD-MAJOR: the
+// V stream of one (row, head) unit of txt_block is one contiguous run of 64-byte records (two keys per cache line).  Eight lanes per
 // (row, head): 8 values each; scale = the smallest 2^e with amax <= 448 * 2^e (exact: amax / 2^(E-8) lies in [256, 512), compared
 // with 448 after an exact scaling), codes round to nearest even; code * scale is a bf16 value.
 namespace {
 __global__ __launch_bounds__(256) void kv_quant_v_kernel(const bf16_t* __restrict__ kv, unsigned char* __restrict__ v8, float* __restrict__ vs,
-                                                         int64_t groups, int D, int H) {
+                                                         int64_t groups, int D, int H, int64_t pitch) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t gi = t >> 3;
     const int sub = (int)(t & 7);
@@ -784,16 +785,16 @@ __global__ __launch_bounds__(256) void kv_quant_v_kernel(const bf16_t* __restric
     q.x = pack_fp8x4(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv);
     q.y = pack_fp8x4(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv);
     if (live) {
-        *(uint2*)(v8 + row * D + head * 64 + sub * 8) = q;
-        if (sub == 0) vs[row * H + head] = scale;
+        *(uint2*)(v8 + ((int64_t)head * pitch + row) * 64 + sub * 8) = q;
+        if (sub == 0) vs[(int64_t)head * pitch + row] = scale;
     }
 }
 }  // namespace
 
-hipError_t launch_kv_quant_v(const bf16_t* kv, unsigned char* v8, float* vs, int rows, int D, int H, hipStream_t s) {
-    if (rows <= 0 || H * 64 != D) return hipErrorInvalidValue;
+hipError_t launch_kv_quant_v(const bf16_t* kv, unsigned char* v8, float* vs, int rows, int D, int H, int64_t pitch, hipStream_t s) {
+    if (rows <= 0 || H * 64 != D || pitch < rows) return hipErrorInvalidValue;
     const int64_t groups = (int64_t)rows * H;
-    hipLaunchKernelGGL(kv_quant_v_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, s, kv, v8, vs, groups, D, H);
+    hipLaunchKernelGGL(kv_quant_v_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, s, kv, v8, vs, groups, D, H, pitch);
     return hipGetLastError();
 }
 

@@ -138,32 +138,15 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
     for (int r = 0; r < 4; ++r) bias[r] = (a.bias && n + r < a.N) ? a.bias[n + r] : 0.f;
 
     const int mtiles = (a.M + 15) >> 4;
-    // the activation fragments of m-tile mt + 1 are requested before the MFMAs of m-tile mt (32 or more rows: a second
-    // m-tile used to add a whole load -> MFMA -> store round trip to the launch)
-    bf16x8 xnext[LNR ? 1 : K32];
-    auto load_x = [&](int mt) {
-        if (LNR) return;
-        int m = mt * 16 + frow;
-        m = m < a.M ? m : a.M - 1;
-        const bf16_t* xp = a.X + (size_t)m * a.ldx + fq * 8;
-#pragma unroll
-        for (int k = 0; k < K32; ++k) xnext[LNR ? 0 : k] = *(const bf16x8*)(xp + k * 32);
-    };
-    load_x(0);
-    for (int mt = 0; mt < mtiles; ++mt) {
+    // one m-tile: fragments of its 16 rows (LNR: the rows the prologue left in LDS), MFMA chain, epilogue
+    auto tile = [&](const int mt, const bf16x8 (&xt)[LNR ? 1 : K32]) {
         int m = mt * 16 + frow;
         const bool mvalid = m < a.M;
         m = mvalid ? m : a.M - 1;                               // clamp: padded rows are discarded
-        bf16x8 xcur[LNR ? 1 : K32];
-        if (!LNR) {
-#pragma unroll
-            for (int k = 0; k < K32; ++k) xcur[k] = xnext[k];
-            if (mt + 1 < mtiles) load_x(mt + 1);
-        }
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < K32; ++k) {
-            const bf16x8 xf = LNR ? *(const bf16x8*)(&xrow[m][fq * 8 + k * 32]) : xcur[LNR ? 0 : k];
+            const bf16x8 xf = LNR ? *(const bf16x8*)(&xrow[m][fq * 8 + k * 32]) : xt[LNR ? 0 : k];
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k], xf, acc, 0, 0, 0);
         }
         // lane holds out[m][n .. n+3]
@@ -195,6 +178,32 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
         } else {  // SK_BIAS_F32: logits (+ arg-max partial of this 16-column tile)
             logits_epilogue(a, y, m, mvalid, n, fq, blockIdx.x, gridDim.x);
         }
+    };
+    auto load_x = [&](int mt, bf16x8 (&xt)[LNR ? 1 : K32]) {
+        if (LNR) return;
+        int m = mt * 16 + frow;
+        m = m < a.M ? m : a.M - 1;
+        const bf16_t* xp = a.X + (size_t)m * a.ldx + fq * 8;
+#pragma unroll
+        for (int k = 0; k < K32; ++k) xt[LNR ? 0 : k] = *(const bf16x8*)(xp + k * 32);
+    };
+    bf16x8 x0[LNR ? 1 : K32];
+    load_x(0, x0);
+    if (LNR || mtiles == 1) {                                   // (LNR: one or two rows = one m-tile)
+        tile(0, x0);
+        return;
+    }
+    // Two or more m-tiles (BASELINE configs[1]: 32 rows; teacher-forced passes): the tiles run in PAIRS, the second of a pair as
+    // straight-line code behind the first, with both tiles' activation fragments requested ahead of the first MFMA chain.  In a
+    // plain loop over the tiles the compiler merges "the weights may still be arriving" with "the previous tile's stores are in
+    // flight" across the back edge and opens every further tile with vmcnt(0) -- a drain of those stores in front of MFMAs whose
+    // operands are all in registers (tools/isa_waits.py: `[ W0 W0`; q|k|v 5.9 us at 32 rows against 4.6 at 16).  Same MFMA chains.
+    bf16x8 x1[LNR ? 1 : K32];
+    for (int mt = 0; mt < mtiles; mt += 2) {
+        load_x(mt + 1 < mtiles ? mt + 1 : mt, x1);              // (an odd tail pair repeats its tile: clamped, nothing stored twice)
+        tile(mt, x0);
+        if (mt + 1 < mtiles) tile(mt + 1, x1);
+        if (mt + 2 < mtiles) load_x(mt + 2, x0);
     }
 }
 
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(256) void skinny_head_kernel(SkinnyArgs a, const in
     for (int r = 0; r < 4; ++r) bias[r] = (a.bias && n + r < a.N) ? a.bias[n + r] : 0.f;
     lstore(0);
     __syncthreads();
-    for (int mt = 0; mt < mtiles; ++mt) {
+    auto step = [&](const int mt) {
         if (mt + 1 < mtiles) gload(mt + 1);
         const char* xb = &xs[mt & 1][frow * PITCH + fq * 16];
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -259,6 +268,13 @@ __global__ __launch_bounds__(256) void skinny_head_kernel(SkinnyArgs a, const in
         logits_epilogue(a, y, m < a.M ? m : a.M - 1, mvalid, n, fq, tile, ntiles);
         if (mt + 1 < mtiles) lstore((mt + 1) & 1);              // the image m-tile mt - 1 was read from: every wave is past the
         __syncthreads();                                         // barrier that closed that iteration
+    };
+    // the m-tiles run in pairs, the second as straight-line code behind the first (see skinny_full_kernel): its weight fragments are
+    // known to be in registers, so its MFMA chain does not open with a drain of the first tile's stores (head: 11.1 us at 32 rows
+    // against 9.2 at 16 before)
+    for (int mt = 0; mt < mtiles; mt += 2) {
+        step(mt);
+        if (mt + 1 < mtiles) step(mt + 1);
     }
 }
 

@@ -240,10 +240,13 @@ __global__ __launch_bounds__(NW * 64, 4) void txt_block_kernel(TxtBlockArgs a) {
     };
     if constexpr (V8) {
         const int S = a.S_img;
-        const unsigned char* v8p = a.v8_img + (size_t)clip * S * D + head * 64 + sub * 8;
-        const float* vsp = a.vs_img + (size_t)clip * S * H + head;
+        // head-major codes: this unit's V stream is one contiguous run of 64-byte records (8 keys = 512 B per wave instruction), its
+        // scales one contiguous run of floats: the 32 scales of a key group are ONE load (lane i: key g0 + (i & 31)), handed to the
+        // lanes of each key by ds_bpermute
+        const unsigned char* v8p = a.v8_img + ((size_t)head * a.v8_pitch + (size_t)clip * S) * 64 + sub * 8;
+        const float* vsp = a.vs_img + (size_t)head * a.v8_pitch + (size_t)clip * S;
         typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-        struct G8 { bf16x8 k[4]; u32x2 v[4]; float sc[4]; bool ok[4]; };
+        struct G8 { bf16x8 k[4]; u32x2 v[4]; float sc; bool ok[4]; };
         auto load8 = [&](int g0, G8& x) {                                  // image keys g0 .. g0 + 31 (past the last: key 0, masked)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -251,12 +254,12 @@ __global__ __launch_bounds__(NW * 64, 4) void txt_block_kernel(TxtBlockArgs a) {
                 x.ok[u] = key < S;
                 key = x.ok[u] ? key : 0;
                 const bf16_t* kp = img + (size_t)key * ld;
-                const u32x2* vp = (const u32x2*)(v8p + (size_t)key * D);
-                const float* sp = vsp + (size_t)key * H;
+                const u32x2* vp = (const u32x2*)(v8p + (size_t)key * 64);
                 x.k[u] = NT_KV ? __builtin_nontemporal_load((const bf16x8*)kp) : *(const bf16x8*)kp;
                 x.v[u] = NT_KV ? __builtin_nontemporal_load(vp) : *vp;
-                x.sc[u] = NT_KV ? __builtin_nontemporal_load(sp) : *sp;
             }
+            const int sk = g0 + (lane & 31);
+            x.sc = vsp[sk < S ? sk : 0];
         };
         auto reduce8 = [&](const G8& x) {
 #pragma clang fp contract(off)
@@ -271,6 +274,9 @@ __global__ __launch_bounds__(NW * 64, 4) void txt_block_kernel(TxtBlockArgs a) {
                 s += __shfl_xor(s, 4);
                 sc[u] = x.ok[u] ? s : -INFINITY;
             }
+            float vsc[4];                                            // (all lanes take part: not under the branch below)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) vsc[u] = __shfl(x.sc, u * 8 + kk);
             const float mt = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
             const float m_new = fmaxf(st.m, mt);
             if (m_new != -INFINITY) {
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(NW * 64, 4) void txt_block_kernel(TxtBlockArgs a) {
                 for (int u = 0; u < 4; ++u) {
                     const float p = ex2(sc[u] - m_new);             // exp2(-inf) = 0 for masked keys
                     st.l += p;
-                    const float pbs = bf2f(f2bf(p)) * x.sc[u];      // P enters the PV product as bf16; x the key's power-of-two scale: exact
+                    const float pbs = bf2f(f2bf(p)) * vsc[u];       // P enters the PV product as bf16; x the key's power-of-two scale: exact
                     typedef __attribute__((ext_vector_type(2))) float f32x2;
                     const f32x2 c01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)x.v[u][0], false), c23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)x.v[u][0], true);
                     const f32x2 c45 = __builtin_amdgcn_cvt_pk_f32_fp8((int)x.v[u][1], false), c67 = __builtin_amdgcn_cvt_pk_f32_fp8((int)x.v[u][1], true);
