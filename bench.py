@@ -588,10 +588,7 @@ def main():
     # ---- per-kernel-class timing: HIP events recorded by the library on its launch stream ----
     roofline, breakdown = None, None
     if not args.no_profile and not args.plain:
-        # The brackets need one batch at a time (synchronous calls).  Synchronous calls would take 224-row GEMM tiles
-        # (a latency lever the pipelined submissions do not use: docs/LAB_NOTEBOOK.md par. 6), so that switch is turned off for this
-        # pass: what is bracketed is gemm256_kernel, the kernel the timed (pipelined) region above ran.
-        old224 = model._lib.gitcap_dbg_config(4, 0)
+        # The brackets need one batch at a time (synchronous calls); the kernels are those of the pipelined path.
         model.profile(True)
         nprof = min(args.steps, 5)
         for i in range(nprof):
@@ -599,7 +596,6 @@ def main():
         torch.cuda.synchronize(dev)
         prof = model.profile_read()
         model.profile(False)
-        model._lib.gitcap_dbg_config(4, old224)
         breakdown = {k: {"ms_per_step": round(v["ms"] / nprof, 4), "launches_per_step": v["launches"] // nprof}
                      for k, v in prof.items()}
         # every big-tile GEMM launch: the plain epilogues + the residual GEMMs that also normalise their output rows

@@ -291,8 +291,7 @@ int gitcap_profile_read(gitcap_t* h, int cls, double* ms_total, int64_t* launche
 /* Kernel-level test hooks (tests/test_kernels_gpu.py, tools/gemm_bench.py): run ONE kernel on
  * caller-owned device buffers.  gemm: out[m][n] = sum_k A[m][k]*W[n][k] (+epilogue `epi` of
  * csrc/kernels.h: 0 bias->bf16, 1 bias+QuickGELU->bf16, 2 bias+GELU->bf16, 3 bias+resid->f32,
- * 4 bias->f32); A [M][K] bf16, W [N][K] bf16; tile = 64, 128 or 256 (square tiles: M, N multiples of the tile), 224 = the 256(n) x 224(m)
- * kernel (M % 224 == 0, A readable 16 rows past M), 257 = that kernel on 256 rows. */
+ * 4 bias->f32); A [M][K] bf16, W [N][K] bf16; tile = 64, 128 or 256 (square tiles: M, N multiples of the tile). */
 int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float* resid, void* out,
                     int M, int N, int K, int epi, int tile, void* stream);
 /* The fp8 tile kernel (csrc/gemm_f8.hip): A8 [M][K] and W8 [N][K] OCP e4m3 codes (M, N multiples of 256, K of 128), out = acc * ascale *
@@ -301,21 +300,21 @@ int gitcap_dbg_gemm_f8(const void* A8, const void* W8, const float* wscale, floa
                        int M, int N, int K, int epi, float out8_inv, void* stream);
 /* GEMM + bias [+ resid] followed by LayerNorm of the output rows (N = 768 or 1024).  post = 0: out_f32 = x = A W^T + bias +
  * resid, out_bf16 = LN(x) (pre-LN block); post = 1: out_f32 = out_bf16 = LN(x), resid may be NULL (post-LN block).
- * fused = 1: inside the 256x256 kernel (the tiles of a 256-row block exchange segment statistics); fused = 224 / 257: inside the
- * 256 x 224 kernel / that kernel on 256 rows (M a multiple of the tile rows); fused = 0: the `tile` kernel, then the row kernel.
- * All produce the same bits (csrc/ln_canon.h). */
+ * fused = 1: inside the 256x256 kernel (the tiles of a 256-row block exchange segment statistics); fused = 0: the `tile` kernel,
+ * then the row kernel.  Both produce the same bits (csrc/ln_canon.h). */
 int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const float* resid, const float* gamma,
                        const float* beta, float eps, float* out_f32, void* out_bf16, int M, int N, int K, int post,
                        int fused, int tile, void* stream);
 /* Speed-only switches at run time (what the GITCAP_* environment variables set once per process; INTEGRATION.md par. 9), so that
  * one process can check that results do not depend on them.  key 0: GEMM + LayerNorm epilogue on/off; 1: one/two-row prologue
- * on/off; 2: 256x256-tile threshold; 3: 128x128-tile threshold; 4: 224-row tiles for synchronous calls on/off; 5: the greedy loop's
+ * on/off; 2: 256x256-tile threshold; 3: 128x128-tile threshold; 4: retired (was: 224-row tiles for synchronous calls; accepted, no effect); 5: the greedy loop's
  * arg-max launch also embeds the next step's input rows on/off; 6: polls a fused GEMM + LayerNorm workgroup waits for its
  * siblings before it gives up (0 = default; 1 forces the fail-soft path of gitcap_poll_errors in a test); 7: the text rows'
  * FC1 -> GELU -> FC2 as one launch over hidden slices on/off; 8: fragment-major copies of the text-path weights at the next
  * gitcap_finalize_weights on/off; 9: 8-wave workgroups for text-attention launches of more (row, head) units than CUs on/off;
  * 10: the vocabulary head's four-tile workgroups that share the activation rows through LDS on/off; 11: three-wave workgroups
- * that share the slab reduce of the one/two-row prologue on/off.  Returns the previous value (< 0: bad key).  The switches are process-wide atomics: a call on another thread sees either value,
+ * that share the slab reduce of the one/two-row prologue on/off; 12: one/two rows: the arg-max of token step t inside the q|k|v
+ * launch of step t + 1 (one launch less per step) on/off.  Returns the previous value (< 0: bad key).  The switches are process-wide atomics: a call on another thread sees either value,
  * and either value gives the same bits. */
 int gitcap_dbg_config(int key, int value);
 /* attn_full: qkv [G*S][3*H*64] bf16 -> ctx [G*S][H*64] bf16 */

@@ -19,7 +19,7 @@
 #define GITCAP_ABI_VERSION 1
 // (tools/build_diag.py redefines this to reach the experimental tile kernels of tools/experiments/)
 #ifndef GITCAP_DBG_GEMM_DISPATCH
-#define GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, s) ((tile) == 256 ? launch_gemm256(a, epi, s) : (tile) == 64 ? launch_gemm64(a, epi, s) : (tile) == 224 ? launch_gemm_mt(a, epi, 224, s) : (tile) == 257 ? launch_gemm_mt(a, epi, 256, s) : launch_gemm(a, epi, s))
+#define GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, s) ((tile) == 256 ? launch_gemm256(a, epi, s) : (tile) == 64 ? launch_gemm64(a, epi, s) : launch_gemm(a, epi, s))
 #endif
 
 // Speed-only switches (results do not depend on them: tests/test_parity_gpu.py).  Process-wide, set once from the
@@ -29,6 +29,7 @@
 std::atomic<bool> g_row_prologue{!env_flag("GITCAP_NO_ROW_PROLOGUE")};
 std::atomic<bool> g_head_share{!env_flag("GITCAP_NO_HEAD_SHARE")};        // kernels.h; gitcap_dbg_config(10, .)
 std::atomic<bool> g_rows3{!env_flag("GITCAP_NO_ROWS3")};                  // kernels.h; gitcap_dbg_config(11, .)
+std::atomic<bool> g_argmax_fold{!env_flag("GITCAP_NO_ARGMAX_FOLD")};      // kernels.h; gitcap_dbg_config(12, .)
 
 // compute units of the current device, cached per device (the workgroup -> tile maps and the tile-height choice depend on it)
 int device_cus() {
@@ -190,17 +191,12 @@ std::atomic<int> g_small_tiles{getenv("GITCAP_GEMM_SMALL_TILES") ? atoi(getenv("
 // 128x128-tile count below which the 64x64 kernel is used (GITCAP_GEMM_TINY_TILES=0 disables the switch)
 std::atomic<int> g_tiny_tiles{getenv("GITCAP_GEMM_TINY_TILES") ? atoi(getenv("GITCAP_GEMM_TINY_TILES")) : 200};     // measured crossover (tools/gemm_tiles_small.py): 180 -> 64x64, 228 -> 128x128
 
-// 224-row tiles where they save rounds (host_logic.h: pick_tile_rows).  GITCAP_NO_TILE224=1 / gitcap_dbg_config(4, 0): never.
-// They are a LATENCY lever: a synchronous call (one batch alone on the chip) gains 1.4 % at the bench shape, but in the
-// pipeline the CUs a 256-row launch leaves idle (34 of 256 at N = 768, the partial last round of the wider GEMMs) are
-// what the token loops of the batches in flight run on: with 224-row tiles everywhere the pipelined bench LOSES 4 %
-// (1670 vs 1742 captions/s, same box).  So submissions (gitcap_greedy_submit) keep 256-row tiles unless
-// GITCAP_TILE224_PIPELINED is set (1: every big launch, 2: only launches of several rounds; experiment switch).
-std::atomic<bool> g_tile224{!env_flag("GITCAP_NO_TILE224")};
+// (Until round 5 synchronous calls took 256(n) x 224(m) tiles -- a second tile kernel, gemm_mt.hip, 548 lines -- where that turned
+// partial rounds on the 256 CUs into full ones: -1 ... -2 % per one-batch-at-a-time step, nothing for the pipelined path, whose idle
+// CUs feed the token loops.  Retired in round 6: tools/experiments/gemm_mt.hip, profiles/r03_*, docs/LAB_NOTEBOOK.md.)
 // polls a tile of a fused GEMM + LayerNorm launch spends waiting for its siblings before it gives up (0 = LN_SPIN_DEFAULT,
 // ~30 s).  gitcap_dbg_config(6, n): a test forces the give-up path with n = 1.
 std::atomic<unsigned> g_ln_spin_limit{0};
-const int g_tile224_pipe = getenv("GITCAP_TILE224_PIPELINED") ? atoi(getenv("GITCAP_TILE224_PIPELINED")) : 0;
 
 int fail(const gitcap* h, int code, const std::string& msg) {
     if (h) h->err = msg; else g_create_err = msg;
@@ -301,10 +297,8 @@ int ln(gitcap* h, hipStream_t s, const float* x, int ldx, const float* g, const 
 // Tile kernel selection.  `rows` = the valid rows of the launch; a.M comes in as rows padded to 256.  Few 256x256 tiles
 // (small batches: one 6-frame clip is 5 x 3..12 tiles for 256 CUs) leave most of the chip idle: below g_small_tiles
 // tiles the 128x128 kernel (4x the workgroups, two per CU) is used (B=1: 7.7 -> 6.8 ms per caption), and below
-// g_tiny_tiles of THOSE the 64x64 kernel (16x, three per CU, 3-stage ring: the single-clip launches).  Big launches
-// take 256(n) x 224(m) tiles where that turns partial rounds on the 256 CUs into full ones (the bench shape: every GEMM,
-// -3 ... -5 % per launch measured; synchronous calls only, see g_tile224).  All tile kernels produce bitwise identical results (tests/test_kernels_gpu.py), so the choice
-// only affects speed.
+// g_tiny_tiles of THOSE the 64x64 kernel (16x, three per CU, 3-stage ring: the single-clip launches).  All tile kernels
+// produce bitwise identical results (tests/test_kernels_gpu.py), so the choice only affects speed.
 // Weights: bf16, or e4m3 bytes + row scales (W.scale != nullptr).  The tile kernels read e4m3 panels through bf16
 // staging (a few MB: it stays in L2 / the Infinity Cache; HBM sees the e4m3 bytes): the four matrices of a transformer
 // layer are expanded by ONE launch at the head of the layer (stage_layer), anything else right before its GEMM.
@@ -327,21 +321,14 @@ hipError_t resolve_weight(gitcap* h, const WRef& W, int N, int K, hipStream_t s,
     return e;
 }
 
-// `rows` = the valid rows of the launch (a.M = rows padded to 256); `cap` = rows of the A / output buffers (h->Mi, or h->Pp
-// for the patch GEMM): a launch on 224-row tiles covers ceil224(rows) rows and its LDS-DMA pieces read 16 further.
+// `rows` = the valid rows of the launch (a.M = rows padded to 256)
 hipError_t launch_gemm_auto(gitcap* h, GemmArgs a, int epi, hipStream_t s, int rows, int cap) {
+    (void)rows; (void)cap;
     const bool ln = epi == EPI_RESID_LN_PRE || epi == EPI_RESID_LN_POST;
     if (ln) { a.ln_fail = h->ln_fail; a.ln_spin_limit = g_ln_spin_limit; }
     if (a.wscale) return launch_gemm256f8(a, epi, s);                 // e4m3 operands: one tile kernel, whatever the batch
     if (a.ln_out8 && ln) return launch_gemm256(a, epi, s);            // (its e4m3 LayerNorm copy: 256-row tiles only)
-    if (gemm256_ok(a) && (a.M >> 8) * (a.N >> 8) >= g_small_tiles) {
-        const bool allow224 = g_tile224 && (!h->pipelined || g_tile224_pipe == 1 || (g_tile224_pipe == 2 && (a.M >> 8) * (a.N >> 8) > h->cus));
-        const int m224 = (rows + 223) / 224 * 224;
-        const bool t224 = allow224 && rows > 0 && pad_to(rows, 256) == a.M && m224 + 16 <= cap &&
-                          pick_tile_rows(rows, a.N, ln, h->cus) == 224;
-        if (t224) a.M = m224;
-        return t224 ? launch_gemm_mt(a, epi, 224, s) : launch_gemm256(a, epi, s);
-    }
+    if (gemm256_ok(a) && (a.M >> 8) * (a.N >> 8) >= g_small_tiles) return launch_gemm256(a, epi, s);
     if (ln) return hipErrorInvalidValue;
     if ((a.M & 63) == 0 && (a.N & 63) == 0 && ((a.M & 127) || (a.N & 127) || (a.M >> 7) * (a.N >> 7) < g_tiny_tiles))
         return launch_gemm64(a, epi, s);
@@ -549,9 +536,12 @@ bool text_chain_ok(gitcap* h, int rows, int T) {
            !(g_row_prologue && skinny_row_prologue_ok(rows, h->D, h->dec[0].qkvw.scale != nullptr));
 }
 
+// fold_prev / defer_argmax (one or two rows, greedy loop; see text_fold_ok): the arg-max over this step's head partials is NOT
+// launched (defer_argmax) -- the next step's q|k|v launch of layer 0 takes the token from the partials itself (fold_prev: row
+// prologue kind 3), stores it to ids[r * ld_ids] and counts SEP tokens under `step - 1`.
 int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams, int t0, int T, float* logits_out,
                  int all_positions, int64_t* argmax_out, int ld_argmax, int32_t* sep_cnt, int step, hipStream_t s,
-                 bool pre_embedded = false, bool embed_next = false) {
+                 bool pre_embedded = false, bool embed_next = false, bool fold_prev = false, bool defer_argmax = false) {
     const gitcap_config& c = h->c;
     if (!h->finalized) return fail(h, GITCAP_ERR_STATE, "weights not finalized");
     if (!h->have_image) return fail(h, GITCAP_ERR_STATE, "text_forward before encode/set_visual");
@@ -582,6 +572,11 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     // The residual rows then alternate between two buffers (workgroup 0 writes them while the others still read the old).
     const bool rows_pro = g_row_prologue && !hid && skinny_row_prologue_ok(M, D, h->dec[0].qkvw.scale != nullptr);
     float *xcur = h->xs, *xalt = h->xs2;
+    if (fold_prev && !rows_pro) {        // (a speed switch was flipped between two steps of one loop: the deferred arg-max runs on its own)
+        HIP_OK(h, launch_argmax_final(h->amax_val, h->amax_idx, (c.vocab_size + 15) / 16, rows, 1, 0, const_cast<int64_t*>(ids), ld_ids,
+                                      sep_cnt, step - 1, c.sep_token_id, s, nullptr));
+        fold_prev = false;
+    }
     for (int l = 0; l < c.dec_layers; ++l) {
         const DecLayer& L = h->dec[l];
         bf16_t* kvt = h->kv_txt + (size_t)l * kvt_layer;
@@ -592,6 +587,10 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
             if (l == 0) {
                 a.ln.kind = 2; a.ln.ids = ids; a.ln.ld_ids = ld_ids; a.ln.T = T; a.ln.t0 = t0; a.ln.vocab = c.vocab_size;
                 a.ln.word = h->word; a.ln.pos = h->tpos; a.ln.g = h->txt_lnw; a.ln.b = h->txt_lnb;
+                if (fold_prev) {
+                    a.ln.kind = 3; a.ln.am_val = h->amax_val; a.ln.am_idx = h->amax_idx; a.ln.am_ntiles = (c.vocab_size + 15) / 16;
+                    a.ln.ids_w = const_cast<int64_t*>(ids); a.ln.sep_cnt = sep_cnt; a.ln.sep_step = step - 1; a.ln.sep_id = c.sep_token_id;
+                }
             } else {
                 const DecLayer& P = h->dec[l - 1];
                 a.ln.kind = 1; a.ln.slabs = h->slabs; a.ln.nslab = ks_f; a.ln.bias = P.fc2b; a.ln.resid = xcur; a.ln.g = P.ln2w; a.ln.b = P.ln2b;
@@ -659,7 +658,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
         ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * ha.M * V * D, (ha.wscale ? 1.0 : 2.0) * V * D);
         HIP_OK(h, launch_skinny(ha, SK_BIAS_F32, s));
     }
-    if (argmax_out) {
+    if (argmax_out && !defer_argmax) {
         const NextEmbed ne{h->word, h->tpos, h->txt_lnw, h->txt_lnb, c.dec_ln_eps, D, c.vocab_size, t0 + 1, h->xs, h->xsb};
         HIP_OK(h, launch_argmax_final(h->amax_val, h->amax_idx, ntiles, rows, am_stride, am_off, argmax_out, ld_argmax,
                                       sep_cnt, step, c.sep_token_id, s, embed_next ? &ne : nullptr));
@@ -768,7 +767,7 @@ int gitcap_create(const gitcap_config* cfg, int device, gitcap_t** out) {
     h->Kp = pad_to(3 * c.patch_size * c.patch_size, 64);
     h->Dv = c.enc_width; h->D = c.dec_width; h->V = c.vocab_size; h->Vp = pad_to(c.vocab_size, 16);
     h->Smax = c.max_frames * h->N;
-    // + 256 rows: a launch on 224-row tiles covers up to 223 rows more than the valid ones and its LDS-DMA pieces read 16 further
+    // (+ 256 rows of slack: once needed by the retired 224-row tiles; kept so that the buffer sizes of round 5 stay what they were)
     h->Mi = pad_to(c.max_batch * h->Smax, 256) + 256;
     h->Pp = pad_to(c.max_batch * c.max_frames * h->G * h->G, 256) + 256;
     h->R = c.max_batch * c.max_beams; h->Tmax = c.max_text_len;
@@ -1173,11 +1172,17 @@ int gitcap_text_forward(gitcap_t* h, const int64_t* ids, int ld_ids, int rows, i
 // token steps 0 .. max_len-1 of `rows` text rows (the image K/V of their clips at h->kv_img), ids at ids_out (row pitch ld)
 static int greedy_rows(gitcap* h, int rows, int max_len, int64_t* ids_out, int ld, hipStream_t s) {
     const bool chain = text_chain_ok(h, rows, 1);
+    // one or two rows (the q|k|v launch of layer 0 computes its input rows itself): the arg-max of step t runs inside that launch of
+    // step t + 1 -- one launch less per token step; the last step keeps its own arg-max launch
+    const bool fold = g_argmax_fold && g_row_prologue && !(h->want_hidden && h->cur_slot == 0 && !h->pipelined) &&
+                      skinny_row_prologue_ok(rows, h->D, h->dec[0].qkvw.scale != nullptr);
     bool have_rows = false;                                  // the previous step's arg-max launch embedded this step's input rows
     for (int t = 0; t < max_len; ++t) {
         // forward on the sequence so far, argmax of the last position, append (model.py:173-182)
         const bool next = chain && t + 1 < max_len && t + 1 < h->c.max_text_pos;
-        const int rc = text_forward(h, ids_out + t, ld, rows, 1, t, 1, nullptr, 0, ids_out + t + 1, ld, h->sep_cnt, t, s, have_rows, next);
+        const bool defer = fold && t + 1 < max_len;
+        const int rc = text_forward(h, ids_out + t, ld, rows, 1, t, 1, nullptr, 0, ids_out + t + 1, ld, h->sep_cnt, t, s, have_rows, next,
+                                    fold && t > 0, defer);
         if (rc) return rc;
         have_rows = next;
     }
@@ -1429,7 +1434,7 @@ int gitcap_dbg_gemm(const void* A, const void* W, const float* bias, const float
     a.A = (const bf16_t*)A; a.lda = K; a.W = (const bf16_t*)W; a.bias = bias; a.M = M; a.N = N; a.K = K;
     a.out = out; a.ldo = N; a.resid = resid; a.ldr = N;
     if (epi < 0 || epi > EPI_BIAS_F32) return GITCAP_ERR_ARG;
-    if (tile != 64 && tile != 128 && tile != 256 && tile != 224 && tile != 257) return GITCAP_ERR_ARG;
+    if (tile != 64 && tile != 128 && tile != 256) return GITCAP_ERR_ARG;
     hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, (hipStream_t)stream);
     return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
 }
@@ -1480,26 +1485,20 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
     const int epi = post ? EPI_RESID_LN_POST : EPI_RESID_LN_PRE;
     if (!post && !resid) return GITCAP_ERR_ARG;
     hipError_t e;
-    if (fused == 1) {                               // the 256x256 kernel of gemm256.hip
-        if (!gemm256_ln_ok(a)) return GITCAP_ERR_ARG;
-        e = launch_gemm256(a, epi, s);
-    } else {                                        // fused = 224 / 257: gemm_mt.hip on 224- / 256-row tiles
-        const int tr = fused == 257 ? 256 : fused;
-        if (!gemm_mt_ln_ok(a, tr)) return GITCAP_ERR_ARG;
-        e = launch_gemm_mt(a, epi, tr, s);
-    }
+    if (fused != 1 || !gemm256_ln_ok(a)) return GITCAP_ERR_ARG;          // the 256x256 kernel of gemm256.hip
+    e = launch_gemm256(a, epi, s);
     return e == hipSuccess ? 0 : GITCAP_ERR_HIP;
 }
 
 // Speed-only switches at run time (the same ones the GITCAP_* environment variables set once per process): lets ONE process
 // check that results do not depend on them.  key 0: GEMM + LayerNorm epilogue on/off, 1: one/two-row prologue on/off,
-// 2: 256-tile threshold (GITCAP_GEMM_SMALL_TILES), 3: 128-tile threshold (GITCAP_GEMM_TINY_TILES), 4: 224-row tiles on/off,
+// 2: 256-tile threshold (GITCAP_GEMM_SMALL_TILES), 3: 128-tile threshold (GITCAP_GEMM_TINY_TILES), 4: retired (no effect),
 // 5: greedy loop chains token steps (the arg-max launch embeds the next step's input rows) on/off,
 // 6: polls a fused GEMM + LayerNorm tile waits for its siblings before it gives up (0 = default; 1 forces the fail-soft path),
 // 7: text rows' FC1 -> GELU -> FC2 as one launch over hidden slices (ffn_txt.hip) on/off,
 // 8: gitcap_finalize_weights makes fragment-major copies of the text-path weights on/off (takes effect at the next finalize),
 // 9: text attention launches of more units than CUs use 8-wave workgroups (two units per CU) on/off,
-// 10 / 11: see include/gitcap.h.
+// 10 / 11: see include/gitcap.h, 12: one/two rows: the arg-max of step t inside the q|k|v launch of step t + 1 on/off.
 // Returns the old value.
 int gitcap_dbg_config(int key, int value) {
     int old = -1;
@@ -1508,7 +1507,7 @@ int gitcap_dbg_config(int key, int value) {
         case 1: old = g_row_prologue.exchange(value != 0); break;
         case 2: old = g_small_tiles.exchange(value); break;
         case 3: old = g_tiny_tiles.exchange(value); break;
-        case 4: old = g_tile224.exchange(value != 0); break;
+        case 4: old = 0; break;                                   // (retired: 224-row GEMM tiles for synchronous calls)
         case 5: old = g_chain_steps.exchange(value != 0); break;
         case 6: old = (int)g_ln_spin_limit.exchange((unsigned)(value > 0 ? value : 0)); break;
         case 7: old = g_ffn_fuse.exchange(value != 0); break;
@@ -1516,6 +1515,7 @@ int gitcap_dbg_config(int key, int value) {
         case 9: old = g_txt8.exchange(value != 0); break;
         case 10: old = g_head_share.exchange(value != 0); break;
         case 11: old = g_rows3.exchange(value != 0); break;
+        case 12: old = g_argmax_fold.exchange(value != 0); break;
         default: return GITCAP_ERR_ARG;
     }
     return old;

@@ -157,21 +157,6 @@ GITCAP_HD inline bool ln_tile_of_block(int bid, int nrb, int ntn, int* tm, int* 
     return true;
 }
 
-// ---- tile height of a big-tile GEMM launch -----------------------------------------------------------------------------
-// One workgroup per CU, 256 CUs: a launch runs in whole rounds, so its K-loop time goes as rounds x tile rows.  224-row
-// tiles turn the bench shape's 0.87 / 2.6 / 3.47 rounds of 256-row tiles into 1 / 3 / 4 full rounds of 7/8 the work
-// (gemm_mt.hip).  Speed only: both heights give the same bits.
-inline long tile_rounds_cost(int rows, int ntn, int bm, bool ln, int cus = 256) {
-    const int nrb = (rows + bm - 1) / bm, tiles = nrb * ntn;
-    const int per_xcd = cus >= 8 ? cus / 8 : 1;                               // the workgroup -> tile maps deal over 8 dispatch sequences
-    long rounds = (tiles + cus - 1) / cus;
-    if (ln && tiles > cus) rounds = (((nrb + 7) >> 3) * ntn + per_xcd - 1) / per_xcd;   // whole row blocks per XCD
-    return rounds * bm;
-}
-inline int pick_tile_rows(int rows, int N, bool ln, int cus = 256) {
-    return tile_rounds_cost(rows, N >> 8, 224, ln, cus) < tile_rounds_cost(rows, N >> 8, 256, ln, cus) ? 224 : 256;
-}
-
 // ---- health of the GEMM + LayerNorm statistics exchange -------------------------------------------------------------------
 // A tile of a fused launch waits (bounded) for the sibling tiles of its row block; if the bound is ever hit -- the siblings
 // cannot become resident, e.g. a foreign process or a CU-masked stream holds the CUs (co-residency) -- the

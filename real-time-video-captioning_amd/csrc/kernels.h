@@ -59,11 +59,6 @@ hipError_t launch_gemm256(const GemmArgs& a, int epi, hipStream_t s);   // 256x2
 bool gemm256_ln_ok(const GemmArgs& a);                                   // shape the EPI_RESID_LN_* epilogues accept
 bool gemm256f8_ok(const GemmArgs& a);                                    // fp8 operands: K % 128 == 0, wscale / ascale set
 hipError_t launch_gemm256f8(const GemmArgs& a, int epi, hipStream_t s);  // the same tile kernel on e4m3 operands (gemm_f8.hip)
-// 256(n) x tile_rows(m) tile, tile_rows = 224 or 256 (gemm_mt.hip): M % tile_rows == 0; with 224 the A buffer must be readable
-// 16 rows past M.  Same bits as every other tile kernel.
-bool gemm_mt_ok(const GemmArgs& a, int tile_rows);
-bool gemm_mt_ln_ok(const GemmArgs& a, int tile_rows);
-hipError_t launch_gemm_mt(const GemmArgs& a, int epi, int tile_rows, hipStream_t s);
 
 // ---- skinny GEMMs (text rows; M = a few 16-row tiles): weight streaming, one wave per tile ----
 enum SkinnyEpi { SK_BIAS_BF16 = 0, SK_BIAS_GELU_BF16 = 1, SK_BIAS_RELU_BF16 = 2, SK_BIAS_F32 = 3 };
@@ -80,7 +75,8 @@ struct SkinnyArgs {
     // itself -- the LayerNorm that would otherwise be the launch in front of this one -- while its weight fragments are
     // in flight; X is not read.  Workgroup 0 also writes the fp32 rows to xf (must not alias resid).
     struct RowPrologue {
-        int kind;                          // 0 none, 1 split-K slabs + bias + residual -> LayerNorm, 2 text embedding -> LayerNorm
+        int kind;                          // 0 none, 1 split-K slabs + bias + residual -> LayerNorm, 2 text embedding -> LayerNorm,
+                                           // 3 = 2 with the token taken from the previous step's vocabulary-head partials (below)
         const float* slabs; int nslab;     // kind 1
         const float *bias, *resid;
         const int64_t* ids;                // kind 2
@@ -88,6 +84,11 @@ struct SkinnyArgs {
         const float *word, *pos;
         const float *g, *b; float eps;     // LayerNorm
         float* xf;                         // [M][K]
+        // kind 3 (greedy loop, one position per row): the row's token = arg-max over the per-tile partials the previous step's
+        // vocabulary head left (max value, smallest index among equals: launch_argmax_final's rule); workgroup 0 also stores it
+        // to ids_w[m * ld_ids] and counts SEP tokens in sep_cnt[sep_step] -- the arg-max launch of the previous step, folded in
+        const float* am_val; const int* am_idx; int am_ntiles;
+        int64_t* ids_w; int32_t* sep_cnt; int sep_step, sep_id;
     } ln;
     // optional fragment-major copy of W (launch_pack_frags: [tile][k32][lane][8]); when set the kernels read it instead of W
     const void* Wpk;
@@ -100,6 +101,9 @@ extern std::atomic<bool> g_head_share;
 // one/two-row prologue over more than 16 slabs: three-wave workgroups that share the reduce (skinny.hip: skinny_rows3_kernel);
 // GITCAP_NO_ROWS3 / gitcap_dbg_config(11, 0): the single-wave form.  Same bits either way.
 extern std::atomic<bool> g_rows3;
+// one/two rows: the arg-max of token step t runs inside the q|k|v launch of step t + 1 (row prologue kind 3; one launch less per
+// step); GITCAP_NO_ARGMAX_FOLD / gitcap_dbg_config(12, 0): the stand-alone arg-max launch.  Same bits either way.
+extern std::atomic<bool> g_argmax_fold;
 bool skinny_row_prologue_ok(int M, int K, bool fp8);         // shapes the row-prologue form is instantiated for
 hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s);
 bool skinny_full_ok(int K);                                  // K depths launch_skinny is instantiated for

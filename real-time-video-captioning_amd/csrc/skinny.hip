@@ -98,7 +98,9 @@ __device__ __forceinline__ void logits_epilogue(const SkinnyArgs& a, const float
     }
 }
 
-template <int K32, int EPI, bool FP8, bool LNR>
+// AMX (with LNR): the row prologue of kind 3 -- the token comes from the previous step's vocabulary-head partials (an instantiation of
+// its own: in the common one the scan's registers cost the kind 1 / 2 prologues a spill)
+template <int K32, int EPI, bool FP8, bool LNR, bool AMX = false>
 __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
     const int lane = threadIdx.x;
     const int frow = lane & 15, fq = lane >> 4;
@@ -113,8 +115,42 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
             f32x4 v[NV], gv[NV], bev[NV];
             row_load_vec<NV>(gv, p.g, a.K, lane);                // gamma / beta: requested ahead of the row's own loads
             row_load_vec<NV>(bev, p.b, a.K, lane);
-            const float s = p.kind == 1 ? row_load_reduce<NV>(v, p.slabs, p.nslab, p.bias, p.resid, a.M, a.K, m, lane)
-                                        : row_load_embed<NV>(v, p.ids, p.ld_ids, p.T, p.t0, p.word, p.pos, a.K, p.vocab, m, lane);
+            float s;
+            if constexpr (AMX) {
+                // the token of row m: arg-max over the previous step's head partials (order independent: max value, smallest index
+                // among equals), 8 pairs per lane and round trip; every workgroup computes it, workgroup 0 publishes it
+                float best = -INFINITY;
+                int bi = 0x7fffffff;
+                const size_t base = (size_t)m * p.am_ntiles;
+                for (int i0 = lane; i0 < p.am_ntiles; i0 += 64 * 8) {
+                    float v8[8];
+                    int j8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = min(i0 + 64 * u, p.am_ntiles - 1);           // (past the end: the last tile again)
+                        v8[u] = p.am_val[base + i];
+                        j8[u] = p.am_idx[base + i];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (v8[u] > best || (v8[u] == best && j8[u] < bi)) { best = v8[u]; bi = j8[u]; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float v2 = __shfl_xor(best, o);
+                    const int i2 = __shfl_xor(bi, o);
+                    if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
+                }
+                if (bi == 0x7fffffff) bi = 0;
+                if (blockIdx.x == 0 && lane == 0) {
+                    p.ids_w[(size_t)m * p.ld_ids] = bi;
+                    if (p.sep_cnt && bi == p.sep_id) atomicAdd(&p.sep_cnt[p.sep_step], 1);
+                }
+                s = row_load_embed_tok<NV>(v, (int64_t)bi, p.t0, p.word, p.pos, a.K, p.vocab, lane);
+            } else {
+                s = p.kind == 1 ? row_load_reduce<NV>(v, p.slabs, p.nslab, p.bias, p.resid, a.M, a.K, m, lane)
+                                : row_load_embed<NV>(v, p.ids, p.ld_ids, p.T, p.t0, p.word, p.pos, a.K, p.vocab, m, lane);
+            }
             row_layernorm_v<NV>(v, s, lane, a.K, p.eps, gv, bev);
             row_store<NV>(v, lane, a.K, blockIdx.x == 0 ? p.xf + (size_t)m * a.K : nullptr, (bf16_t*)nullptr);
 #pragma unroll
@@ -138,15 +174,32 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
     for (int r = 0; r < 4; ++r) bias[r] = (a.bias && n + r < a.N) ? a.bias[n + r] : 0.f;
 
     const int mtiles = (a.M + 15) >> 4;
-    // one m-tile: fragments of its 16 rows (LNR: the rows the prologue left in LDS), MFMA chain, epilogue
-    auto tile = [&](const int mt, const bf16x8 (&xt)[LNR ? 1 : K32]) {
+    // the activation fragments of m-tile mt + 1 are requested before the MFMAs of m-tile mt (32 or more rows: a second
+    // m-tile used to add a whole load -> MFMA -> store round trip to the launch)
+    bf16x8 xnext[LNR ? 1 : K32];
+    auto load_x = [&](int mt) {
+        if (LNR) return;
+        int m = mt * 16 + frow;
+        m = m < a.M ? m : a.M - 1;
+        const bf16_t* xp = a.X + (size_t)m * a.ldx + fq * 8;
+#pragma unroll
+        for (int k = 0; k < K32; ++k) xnext[LNR ? 0 : k] = *(const bf16x8*)(xp + k * 32);
+    };
+    load_x(0);
+    for (int mt = 0; mt < mtiles; ++mt) {
         int m = mt * 16 + frow;
         const bool mvalid = m < a.M;
         m = mvalid ? m : a.M - 1;                               // clamp: padded rows are discarded
+        bf16x8 xcur[LNR ? 1 : K32];
+        if (!LNR) {
+#pragma unroll
+            for (int k = 0; k < K32; ++k) xcur[k] = xnext[k];
+            if (mt + 1 < mtiles) load_x(mt + 1);
+        }
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < K32; ++k) {
-            const bf16x8 xf = LNR ? *(const bf16x8*)(&xrow[m][fq * 8 + k * 32]) : xt[LNR ? 0 : k];
+            const bf16x8 xf = LNR ? *(const bf16x8*)(&xrow[m][fq * 8 + k * 32]) : xcur[LNR ? 0 : k];
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[k], xf, acc, 0, 0, 0);
         }
         // lane holds out[m][n .. n+3]
@@ -178,32 +231,6 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
         } else {  // SK_BIAS_F32: logits (+ arg-max partial of this 16-column tile)
             logits_epilogue(a, y, m, mvalid, n, fq, blockIdx.x, gridDim.x);
         }
-    };
-    auto load_x = [&](int mt, bf16x8 (&xt)[LNR ? 1 : K32]) {
-        if (LNR) return;
-        int m = mt * 16 + frow;
-        m = m < a.M ? m : a.M - 1;
-        const bf16_t* xp = a.X + (size_t)m * a.ldx + fq * 8;
-#pragma unroll
-        for (int k = 0; k < K32; ++k) xt[LNR ? 0 : k] = *(const bf16x8*)(xp + k * 32);
-    };
-    bf16x8 x0[LNR ? 1 : K32];
-    load_x(0, x0);
-    if (LNR || mtiles == 1) {                                   // (LNR: one or two rows = one m-tile)
-        tile(0, x0);
-        return;
-    }
-    // Two or more m-tiles (BASELINE configs[1]: 32 rows; teacher-forced passes): the tiles run in PAIRS, the second of a pair as
-    // straight-line code behind the first, with both tiles' activation fragments requested ahead of the first MFMA chain.  In a
-    // plain loop over the tiles the compiler merges "the weights may still be arriving" with "the previous tile's stores are in
-    // flight" across the back edge and opens every further tile with vmcnt(0) -- a drain of those stores in front of MFMAs whose
-    // operands are all in registers (tools/isa_waits.py: `[ W0 W0`; q|k|v 5.9 us at 32 rows against 4.6 at 16).  Same MFMA chains.
-    bf16x8 x1[LNR ? 1 : K32];
-    for (int mt = 0; mt < mtiles; mt += 2) {
-        load_x(mt + 1 < mtiles ? mt + 1 : mt, x1);              // (an odd tail pair repeats its tile: clamped, nothing stored twice)
-        tile(mt, x0);
-        if (mt + 1 < mtiles) tile(mt + 1, x1);
-        if (mt + 2 < mtiles) load_x(mt + 2, x0);
     }
 }
 
@@ -254,7 +281,7 @@ __global__ __launch_bounds__(256) void skinny_head_kernel(SkinnyArgs a, const in
     for (int r = 0; r < 4; ++r) bias[r] = (a.bias && n + r < a.N) ? a.bias[n + r] : 0.f;
     lstore(0);
     __syncthreads();
-    auto step = [&](const int mt) {
+    for (int mt = 0; mt < mtiles; ++mt) {
         if (mt + 1 < mtiles) gload(mt + 1);
         const char* xb = &xs[mt & 1][frow * PITCH + fq * 16];
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -268,13 +295,6 @@ __global__ __launch_bounds__(256) void skinny_head_kernel(SkinnyArgs a, const in
         logits_epilogue(a, y, m < a.M ? m : a.M - 1, mvalid, n, fq, tile, ntiles);
         if (mt + 1 < mtiles) lstore((mt + 1) & 1);              // the image m-tile mt - 1 was read from: every wave is past the
         __syncthreads();                                         // barrier that closed that iteration
-    };
-    // the m-tiles run in pairs, the second as straight-line code behind the first (see skinny_full_kernel): its weight fragments are
-    // known to be in registers, so its MFMA chain does not open with a drain of the first tile's stores (head: 11.1 us at 32 rows
-    // against 9.2 at 16 before)
-    for (int mt = 0; mt < mtiles; mt += 2) {
-        step(mt);
-        if (mt + 1 < mtiles) step(mt + 1);
     }
 }
 
@@ -442,7 +462,9 @@ hipError_t launch_full_rows(const SkinnyArgs& a, int epi, hipStream_t s) {
     const SkinnyArgs::RowPrologue& p = a.ln;
     if (!skinny_row_prologue_ok(a.M, a.K, a.wscale != nullptr) || !p.g || !p.b || !p.xf ||
         (p.kind == 1 && (!p.slabs || p.nslab <= 0 || !p.bias || !p.resid || p.resid == p.xf)) ||
-        (p.kind == 2 && (!p.ids || p.T <= 0 || !p.word || !p.pos)) || (p.kind != 1 && p.kind != 2))
+        (p.kind == 2 && (!p.ids || p.T <= 0 || !p.word || !p.pos)) ||
+        (p.kind == 3 && (!p.am_val || !p.am_idx || p.am_ntiles <= 0 || !p.ids_w || p.T != 1 || !p.word || !p.pos)) ||
+        (p.kind != 1 && p.kind != 2 && p.kind != 3))
         return hipErrorInvalidValue;
     const dim3 grid((a.N + 15) / 16);
     // many slabs (the fused FFN's 48): three waves per workgroup share the reduce (skinny_rows3_kernel)
@@ -451,6 +473,11 @@ hipError_t launch_full_rows(const SkinnyArgs& a, int epi, hipStream_t s) {
         if (epi == SK_BIAS_BF16) hipLaunchKernelGGL((skinny_rows3_kernel<K32, SK_BIAS_BF16>), grid3, dim3(192), 0, s, a);
         else if (epi == SK_BIAS_RELU_BF16) hipLaunchKernelGGL((skinny_rows3_kernel<K32, SK_BIAS_RELU_BF16>), grid3, dim3(192), 0, s, a);
         else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
+    if (p.kind == 3) {
+        if (epi != SK_BIAS_BF16) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16, false, true, true>), grid, dim3(64), 0, s, a);
         return hipGetLastError();
     }
     if (epi == SK_BIAS_BF16) hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16, false, true>), grid, dim3(64), 0, s, a);

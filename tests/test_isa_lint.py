@@ -42,7 +42,7 @@ elif _state == "other":
 # (ILi6ELb1 / ILi7ELb1: the opt-in fp8-compute instantiations that also write and count the e4m3 copy of the LayerNorm output)
 SCRATCH_ALLOWED = {"gemm256_kernelILi6ELb1E": 80, "gemm256_kernelILi7ELb1E": 32,
                    "gemm256f8_kernelILi6E": 40, "gemm256f8_kernelILi7E": 32}
-FILES = ["attention.hip", "ffn_txt.hip", "gemm.hip", "gemm256.hip", "gemm_f8.hip", "gemm_mt.hip", "preproc.hip", "rowops.hip",
+FILES = ["attention.hip", "ffn_txt.hip", "gemm.hip", "gemm256.hip", "gemm_f8.hip", "preproc.hip", "rowops.hip",
          "skinny.hip", "student.hip", "txtblock.hip"]
 
 
@@ -71,7 +71,7 @@ def test_no_product_kernel_spills(listings):
             allowed = max([v for k, v in SCRATCH_ALLOWED.items() if k in name] or [0])
             assert scratch is not None and scratch <= allowed, f"{f}: {name} uses {scratch} bytes of scratch (allowed {allowed})"
             assert "xs" not in toks and "xl" not in toks or allowed, f"{f}: {name} has scratch traffic"
-    assert seen >= 150
+    assert seen >= 120
 
 
 def _one(listings, f, pat):

@@ -161,63 +161,6 @@ def test_layernorm_vs_reference(lib, rows, D):
     assert torch.equal(ob, of.bfloat16())
 
 
-@pytest.mark.parametrize("N,K", [(768, 768), (2304, 768), (768, 3072), (1024, 128), (256, 64)])
-def test_gemm_224_row_tiles_bitwise_equal_256(lib, N, K):
-    """gemm_mt.hip: 256(n) x 224(m) tiles (and the same kernel on 256 rows) against the 256x256 product kernel, every plain
-    epilogue, on an M that both heights divide (1792 = 7 x 256 = 8 x 224): same MFMA, ascending k -> the same bits.  Which
-    height runs is decided from the batch size (host_logic.h: pick_tile_rows), so results must not depend on it.  The
-    224-row form reads 16 rows past M (whole DMA pieces): those rows are poisoned with NaN and must not leak."""
-    M = 1792
-    g = torch.Generator(device="cuda").manual_seed(N + K)
-    A = torch.full((M + 16, K), float("nan"), device="cuda").bfloat16()
-    A[:M] = torch.randn(M, K, device="cuda", generator=g).bfloat16()
-    W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
-    bias = torch.linspace(-1, 1, N, device="cuda")
-    resid = torch.randn(M, N, device="cuda", generator=g)
-    for epi, dt in ((0, torch.bfloat16), (1, torch.bfloat16), (2, torch.bfloat16), (3, torch.float32), (4, torch.float32)):
-        outs = []
-        for tile in (256, 224, 257):
-            out = torch.full((M, N), float("nan"), device="cuda", dtype=dt)
-            assert lib.gitcap_dbg_gemm(_p(A), _p(W), _p(bias), _p(resid), _p(out), M, N, K, epi, tile, _stream()) == 0
-            outs.append(out)
-        torch.cuda.synchronize()
-        assert torch.isfinite(outs[0].float()).all()
-        for o in outs[1:]:
-            assert torch.equal(outs[0], o), (epi, N, K)
-    ref = A[:M].float() @ W.float().t() + bias
-    assert torch.allclose(outs[-1], ref, rtol=1e-3, atol=1e-3)          # epi 4 (bias -> f32) against fp32 torch
-
-
-@pytest.mark.parametrize("M,N,K,post", [(1792, 768, 768, 0), (1792, 768, 3072, 1), (1792, 1024, 1024, 1), (19040, 768, 768, 0),
-                                        (19040, 768, 3072, 1), (75264, 768, 768, 1)])
-def test_gemm_224_row_tiles_layernorm_epilogue(lib, M, N, K, post):
-    """The residual + LayerNorm epilogue on 224-row tiles (and the same kernel on 256-row tiles) against the 256x256 kernel's
-    fused epilogue: bitwise.  19040 rows = the bench shape (85 row blocks x 3 tiles = 255 workgroups: one round, plain XCD
-    remap); 75264 rows = 336 row blocks = 1008 workgroups: several rounds, whole row blocks per XCD; run twice (barrier reuse)."""
-    M256 = (M + 255) // 256 * 256
-    g = torch.Generator(device="cuda").manual_seed(M + K)
-    A = torch.zeros(M256 + 16, K, device="cuda", dtype=torch.bfloat16)
-    A[:M256] = torch.randn(M256, K, device="cuda", generator=g).bfloat16()
-    W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
-    bias = torch.randn(N, device="cuda", generator=g)
-    resid = torch.randn(M256, N, device="cuda", generator=g) * 2 + 0.5
-    gamma, beta = torch.randn(N, device="cuda", generator=g), torch.randn(N, device="cuda", generator=g)
-    outs = []
-    for fused, rows in ((1, M256), (224, M), (257, M256)):
-        of = torch.full((M256, N), float("nan"), device="cuda")
-        ob = torch.zeros(M256, N, device="cuda", dtype=torch.bfloat16)
-        for _ in range(2):
-            assert lib.gitcap_dbg_gemm_ln(_p(A), _p(W), _p(bias), _p(resid), _p(gamma), _p(beta), ctypes.c_float(1e-5), _p(of), _p(ob),
-                                          rows, N, K, post, fused, 256, _stream()) == 0
-        torch.cuda.synchronize()
-        outs.append((of[:M], ob[:M]))
-    for of, ob in outs[1:]:
-        assert torch.equal(outs[0][0], of) and torch.equal(outs[0][1], ob)
-    x = A[:M].float() @ W.float().t() + bias + resid[:M]
-    ln = torch.nn.functional.layer_norm(x, (N,), gamma, beta, 1e-5)
-    assert torch.allclose(outs[1][0], ln if post else x, rtol=1e-4, atol=2e-4 * K ** 0.5)
-
-
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 1024, 1024), (768, 4096, 1024), (512, 1024, 4096), (256, 768, 3072)])
 def test_gemm_fp8_vs_fp32_reference(lib, M, N, K):
     """gemm_f8.hip (v_mfma_f32_16x16x128_f8f6f4): e4m3 codes in, exact products, fp32 accumulation -- against the fp32

@@ -39,7 +39,7 @@ patch(os.path.join(dst, 'gemm256.hip'), [
 patch(os.path.join(dst, 'gitcap.hip'), [
     ("    if (tile != 64 && tile != 128 && tile != 256 && tile != 224 && tile != 257) return GITCAP_ERR_ARG;\n    hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, (hipStream_t)stream);",
      "    if (getenv(\"GEMM_DBG_PTR\")) a.pos = (const float*)strtoull(getenv(\"GEMM_DBG_PTR\"), nullptr, 0);\n    hipError_t e = GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, (hipStream_t)stream);"),
-    ("#ifndef GITCAP_DBG_GEMM_DISPATCH\n", "#define GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, s) ((tile) == 258 ? launch_gemm2w(a, epi, s) : (tile) == 260 ? launch_gemm2b(a, epi, s) : (tile) == 259 ? launch_gemm256p(a, epi, s) : (tile) == 256 ? launch_gemm256(a, epi, s) : (tile) == 64 ? launch_gemm64(a, epi, s) : (tile) == 224 ? launch_gemm_mt(a, epi, 224, s) : (tile) == 257 ? launch_gemm_mt(a, epi, 256, s) : launch_gemm(a, epi, s))\n#ifndef GITCAP_DBG_GEMM_DISPATCH\n"),
+    ("#ifndef GITCAP_DBG_GEMM_DISPATCH\n", "#define GITCAP_DBG_GEMM_DISPATCH(tile, a, epi, s) ((tile) == 258 ? launch_gemm2w(a, epi, s) : (tile) == 260 ? launch_gemm2b(a, epi, s) : (tile) == 259 ? launch_gemm256p(a, epi, s) : (tile) == 256 ? launch_gemm256(a, epi, s) : (tile) == 64 ? launch_gemm64(a, epi, s) : launch_gemm(a, epi, s))\n#ifndef GITCAP_DBG_GEMM_DISPATCH\n"),
 ])
 srcs = 'SRCS=' + ' '.join(sorted(f for f in os.listdir(dst) if f.endswith('.hip')))
 subprocess.check_call(['make', '-C', dst, '-j8', srcs])

@@ -1,3 +1,5 @@
+// RETIRED from the product in round 6 (a second full GEMM code path for -1 ... -2 % on synchronous calls only).  Kept as the measured
+// experiment it was: docs/LAB_NOTEBOOK.md round 3, profiles/r03_*.  Builds against csrc/ of commit eba5b05 (kernels.h declared its launchers there).
 // 256(n) x (32*MT)(m) x 64 tile bf16 MFMA GEMM for gfx950, MT = 7 (224 rows) or 8 (256 rows).
 //
 //   C[m][n] = sum_k A[m][k] * W[n][k]  (+ fused epilogue), A and W both K-contiguous.

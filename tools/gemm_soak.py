@@ -1,4 +1,4 @@
-# race screen for the big-tile GEMMs -- gemm256 (default) or, with argv[1] = 224 / 257, gemm_mt.hip on 224- / 256-row tiles
+# race screen for the big-tile GEMMs -- gemm256 (argv[1] = 224 / 257 selected the retired gemm_mt.hip: tools/experiments/)
 # (hand-placed counted vmcnt / staggered barriers): many launches per shape, output
 # poisoned with NaN before every launch, every result compared with the fp32 reference; second pass with a
 # concurrent stream hammering HBM so that DMA arrival times vary

@@ -34,11 +34,11 @@ with open(dst + '_pmc_summary.md', 'w') as f:
             '| kernel | launches | read MB/launch (2x FETCH) | write MB/launch | avg us (profiled) | traffic TB/s | MFMA util | LDS conflict / active |\n|---|---|---|---|---|---|---|---|\n')
     for _, k, n, rd, w, us, tb, util, lds in rows[:18]:
         f.write('| %s | %d | %.1f | %.1f | %.1f | %.2f | %.1f %% | %.1f %% |\n' % (k[:48], n, rd, w, us, tb, 100 * util, 100 * lds))
-g = [k for k in fe if k.startswith('gemm256_kernel') or k.startswith('gemm_mt_kernel')]
+g = [k for k in fe if k.startswith('gemm256_kernel')]
 cat = lambda d, c: [v for k in g for v in d[k][c]]
 fetch, write = mean(cat(fe, 'FETCH_SIZE')), mean(cat(wr, 'WRITE_SIZE'))
 busy, gui = mean(cat(sq, 'SQ_VALU_MFMA_BUSY_CYCLES')), mean(cat(sq, 'GRBM_GUI_ACTIVE'))
-js = {"kernel": "gemm256_kernel (all epilogues), bench.py --serial with GITCAP_NO_TILE224=1 (the kernels of the pipelined path), 4 steps", "source_sha": library_source_sha(), "launches_sampled": len(cat(fe, 'FETCH_SIZE')),
+js = {"kernel": "gemm256_kernel (all epilogues), bench.py --serial (one batch at a time; the kernels are those of the pipelined path), 4 steps", "source_sha": library_source_sha(), "launches_sampled": len(cat(fe, 'FETCH_SIZE')),
       "FETCH_SIZE_KB_avg_raw": round(fetch, 1), "WRITE_SIZE_KB_avg": round(write, 1), "gfx950_fetch_correction": 2.0,
       "traffic_bytes_per_launch": int((2.0 * fetch + write) * 1024), "mfma_busy_cycles_avg": int(busy),
       "grbm_gui_active_sum8xcd_avg": int(gui),

@@ -12,12 +12,6 @@ rocprofv3 --kernel-trace --stats -d $out/stats_pipelined --output-format csv -- 
 echo "stats pipelined done"
 rocprofv3 --kernel-trace --stats -d $out/stats_serial --output-format csv -- $B --serial > $out/bench_serial.json 2> $out/stats_serial.err
 echo "stats serial done"
-# kernel stats of the synchronous path as it runs by default (224-row GEMM tiles: gemm_mt_kernel) ...
-# ... and, like the PMC passes below, with GITCAP_NO_TILE224=1: one batch at a time but the kernels of the PIPELINED path
-# (gemm256_kernel), which is what bench.py's roofline brackets (exported here: the program after -- must be python itself)
-export GITCAP_NO_TILE224=1
-rocprofv3 --kernel-trace --stats -d $out/stats_serial256 --output-format csv -- $B --serial > $out/bench_serial256.json 2> $out/stats_serial256.err
-echo "stats serial (256-row tiles) done"
 P="python3 bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline --plain --serial"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch --output-format csv -- $P > /dev/null 2> $out/pmc_fetch.err
 echo "pmc fetch done"
