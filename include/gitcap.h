@@ -313,8 +313,7 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
  * FC1 -> GELU -> FC2 as one launch over hidden slices on/off; 8: fragment-major copies of the text-path weights at the next
  * gitcap_finalize_weights on/off; 9: 8-wave workgroups for text-attention launches of more (row, head) units than CUs on/off;
  * 10: the vocabulary head's four-tile workgroups that share the activation rows through LDS on/off; 11: three-wave workgroups
- * that share the slab reduce of the one/two-row prologue on/off; 12: one/two rows: the arg-max of token step t inside the q|k|v
- * launch of step t + 1 (one launch less per step) on/off.  Returns the previous value (< 0: bad key).  The switches are process-wide atomics: a call on another thread sees either value,
+ * that share the slab reduce of the one/two-row prologue on/off.  Returns the previous value (< 0: bad key).  The switches are process-wide atomics: a call on another thread sees either value,
  * and either value gives the same bits. */
 int gitcap_dbg_config(int key, int value);
 /* attn_full: qkv [G*S][3*H*64] bf16 -> ctx [G*S][H*64] bf16 */

@@ -29,7 +29,6 @@
 std::atomic<bool> g_row_prologue{!env_flag("GITCAP_NO_ROW_PROLOGUE")};
 std::atomic<bool> g_head_share{!env_flag("GITCAP_NO_HEAD_SHARE")};        // kernels.h; gitcap_dbg_config(10, .)
 std::atomic<bool> g_rows3{!env_flag("GITCAP_NO_ROWS3")};                  // kernels.h; gitcap_dbg_config(11, .)
-std::atomic<bool> g_argmax_fold{!env_flag("GITCAP_NO_ARGMAX_FOLD")};      // kernels.h; gitcap_dbg_config(12, .)
 
 // compute units of the current device, cached per device (the workgroup -> tile maps and the tile-height choice depend on it)
 int device_cus() {
@@ -536,12 +535,9 @@ bool text_chain_ok(gitcap* h, int rows, int T) {
            !(g_row_prologue && skinny_row_prologue_ok(rows, h->D, h->dec[0].qkvw.scale != nullptr));
 }
 
-// fold_prev / defer_argmax (one or two rows, greedy loop; see text_fold_ok): the arg-max over this step's head partials is NOT
-// launched (defer_argmax) -- the next step's q|k|v launch of layer 0 takes the token from the partials itself (fold_prev: row
-// prologue kind 3), stores it to ids[r * ld_ids] and counts SEP tokens under `step - 1`.
 int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams, int t0, int T, float* logits_out,
                  int all_positions, int64_t* argmax_out, int ld_argmax, int32_t* sep_cnt, int step, hipStream_t s,
-                 bool pre_embedded = false, bool embed_next = false, bool fold_prev = false, bool defer_argmax = false) {
+                 bool pre_embedded = false, bool embed_next = false) {
     const gitcap_config& c = h->c;
     if (!h->finalized) return fail(h, GITCAP_ERR_STATE, "weights not finalized");
     if (!h->have_image) return fail(h, GITCAP_ERR_STATE, "text_forward before encode/set_visual");
@@ -572,11 +568,6 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
     // The residual rows then alternate between two buffers (workgroup 0 writes them while the others still read the old).
     const bool rows_pro = g_row_prologue && !hid && skinny_row_prologue_ok(M, D, h->dec[0].qkvw.scale != nullptr);
     float *xcur = h->xs, *xalt = h->xs2;
-    if (fold_prev && !rows_pro) {        // (a speed switch was flipped between two steps of one loop: the deferred arg-max runs on its own)
-        HIP_OK(h, launch_argmax_final(h->amax_val, h->amax_idx, (c.vocab_size + 15) / 16, rows, 1, 0, const_cast<int64_t*>(ids), ld_ids,
-                                      sep_cnt, step - 1, c.sep_token_id, s, nullptr));
-        fold_prev = false;
-    }
     for (int l = 0; l < c.dec_layers; ++l) {
         const DecLayer& L = h->dec[l];
         bf16_t* kvt = h->kv_txt + (size_t)l * kvt_layer;
@@ -587,10 +578,6 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
             if (l == 0) {
                 a.ln.kind = 2; a.ln.ids = ids; a.ln.ld_ids = ld_ids; a.ln.T = T; a.ln.t0 = t0; a.ln.vocab = c.vocab_size;
                 a.ln.word = h->word; a.ln.pos = h->tpos; a.ln.g = h->txt_lnw; a.ln.b = h->txt_lnb;
-                if (fold_prev) {
-                    a.ln.kind = 3; a.ln.am_val = h->amax_val; a.ln.am_idx = h->amax_idx; a.ln.am_ntiles = (c.vocab_size + 15) / 16;
-                    a.ln.ids_w = const_cast<int64_t*>(ids); a.ln.sep_cnt = sep_cnt; a.ln.sep_step = step - 1; a.ln.sep_id = c.sep_token_id;
-                }
             } else {
                 const DecLayer& P = h->dec[l - 1];
                 a.ln.kind = 1; a.ln.slabs = h->slabs; a.ln.nslab = ks_f; a.ln.bias = P.fc2b; a.ln.resid = xcur; a.ln.g = P.ln2w; a.ln.b = P.ln2b;
@@ -658,7 +645,7 @@ int text_forward(gitcap* h, const int64_t* ids, int ld_ids, int rows, int beams,
         ProfScope ps(h, GITCAP_PROF_SKINNY, s, 2.0 * ha.M * V * D, (ha.wscale ? 1.0 : 2.0) * V * D);
         HIP_OK(h, launch_skinny(ha, SK_BIAS_F32, s));
     }
-    if (argmax_out && !defer_argmax) {
+    if (argmax_out) {
         const NextEmbed ne{h->word, h->tpos, h->txt_lnw, h->txt_lnb, c.dec_ln_eps, D, c.vocab_size, t0 + 1, h->xs, h->xsb};
         HIP_OK(h, launch_argmax_final(h->amax_val, h->amax_idx, ntiles, rows, am_stride, am_off, argmax_out, ld_argmax,
                                       sep_cnt, step, c.sep_token_id, s, embed_next ? &ne : nullptr));
@@ -1172,17 +1159,13 @@ int gitcap_text_forward(gitcap_t* h, const int64_t* ids, int ld_ids, int rows, i
 // token steps 0 .. max_len-1 of `rows` text rows (the image K/V of their clips at h->kv_img), ids at ids_out (row pitch ld)
 static int greedy_rows(gitcap* h, int rows, int max_len, int64_t* ids_out, int ld, hipStream_t s) {
     const bool chain = text_chain_ok(h, rows, 1);
-    // one or two rows (the q|k|v launch of layer 0 computes its input rows itself): the arg-max of step t runs inside that launch of
-    // step t + 1 -- one launch less per token step; the last step keeps its own arg-max launch
-    const bool fold = g_argmax_fold && g_row_prologue && !(h->want_hidden && h->cur_slot == 0 && !h->pipelined) &&
-                      skinny_row_prologue_ok(rows, h->D, h->dec[0].qkvw.scale != nullptr);
+    // (Round 6 folded the arg-max of step t into the q|k|v launch of step t + 1 for one / two rows -- one launch less per step, same
+    // bits -- and measured nothing: 4.926 vs 4.912 ms per 20-token caption; tools/experiments/argmax_fold_rows.txt.)
     bool have_rows = false;                                  // the previous step's arg-max launch embedded this step's input rows
     for (int t = 0; t < max_len; ++t) {
         // forward on the sequence so far, argmax of the last position, append (model.py:173-182)
         const bool next = chain && t + 1 < max_len && t + 1 < h->c.max_text_pos;
-        const bool defer = fold && t + 1 < max_len;
-        const int rc = text_forward(h, ids_out + t, ld, rows, 1, t, 1, nullptr, 0, ids_out + t + 1, ld, h->sep_cnt, t, s, have_rows, next,
-                                    fold && t > 0, defer);
+        const int rc = text_forward(h, ids_out + t, ld, rows, 1, t, 1, nullptr, 0, ids_out + t + 1, ld, h->sep_cnt, t, s, have_rows, next);
         if (rc) return rc;
         have_rows = next;
     }
@@ -1498,7 +1481,7 @@ int gitcap_dbg_gemm_ln(const void* A, const void* W, const float* bias, const fl
 // 7: text rows' FC1 -> GELU -> FC2 as one launch over hidden slices (ffn_txt.hip) on/off,
 // 8: gitcap_finalize_weights makes fragment-major copies of the text-path weights on/off (takes effect at the next finalize),
 // 9: text attention launches of more units than CUs use 8-wave workgroups (two units per CU) on/off,
-// 10 / 11: see include/gitcap.h, 12: one/two rows: the arg-max of step t inside the q|k|v launch of step t + 1 on/off.
+// 10 / 11: see include/gitcap.h.
 // Returns the old value.
 int gitcap_dbg_config(int key, int value) {
     int old = -1;
@@ -1515,7 +1498,6 @@ int gitcap_dbg_config(int key, int value) {
         case 9: old = g_txt8.exchange(value != 0); break;
         case 10: old = g_head_share.exchange(value != 0); break;
         case 11: old = g_rows3.exchange(value != 0); break;
-        case 12: old = g_argmax_fold.exchange(value != 0); break;
         default: return GITCAP_ERR_ARG;
     }
     return old;

@@ -75,8 +75,7 @@ struct SkinnyArgs {
     // itself -- the LayerNorm that would otherwise be the launch in front of this one -- while its weight fragments are
     // in flight; X is not read.  Workgroup 0 also writes the fp32 rows to xf (must not alias resid).
     struct RowPrologue {
-        int kind;                          // 0 none, 1 split-K slabs + bias + residual -> LayerNorm, 2 text embedding -> LayerNorm,
-                                           // 3 = 2 with the token taken from the previous step's vocabulary-head partials (below)
+        int kind;                          // 0 none, 1 split-K slabs + bias + residual -> LayerNorm, 2 text embedding -> LayerNorm
         const float* slabs; int nslab;     // kind 1
         const float *bias, *resid;
         const int64_t* ids;                // kind 2
@@ -84,11 +83,6 @@ struct SkinnyArgs {
         const float *word, *pos;
         const float *g, *b; float eps;     // LayerNorm
         float* xf;                         // [M][K]
-        // kind 3 (greedy loop, one position per row): the row's token = arg-max over the per-tile partials the previous step's
-        // vocabulary head left (max value, smallest index among equals: launch_argmax_final's rule); workgroup 0 also stores it
-        // to ids_w[m * ld_ids] and counts SEP tokens in sep_cnt[sep_step] -- the arg-max launch of the previous step, folded in
-        const float* am_val; const int* am_idx; int am_ntiles;
-        int64_t* ids_w; int32_t* sep_cnt; int sep_step, sep_id;
     } ln;
     // optional fragment-major copy of W (launch_pack_frags: [tile][k32][lane][8]); when set the kernels read it instead of W
     const void* Wpk;
@@ -101,9 +95,6 @@ extern std::atomic<bool> g_head_share;
 // one/two-row prologue over more than 16 slabs: three-wave workgroups that share the reduce (skinny.hip: skinny_rows3_kernel);
 // GITCAP_NO_ROWS3 / gitcap_dbg_config(11, 0): the single-wave form.  Same bits either way.
 extern std::atomic<bool> g_rows3;
-// one/two rows: the arg-max of token step t runs inside the q|k|v launch of step t + 1 (row prologue kind 3; one launch less per
-// step); GITCAP_NO_ARGMAX_FOLD / gitcap_dbg_config(12, 0): the stand-alone arg-max launch.  Same bits either way.
-extern std::atomic<bool> g_argmax_fold;
 bool skinny_row_prologue_ok(int M, int K, bool fp8);         // shapes the row-prologue form is instantiated for
 hipError_t launch_skinny(const SkinnyArgs& a, int epi, hipStream_t s);
 bool skinny_full_ok(int K);                                  // K depths launch_skinny is instantiated for

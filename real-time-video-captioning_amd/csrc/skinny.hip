@@ -98,9 +98,7 @@ __device__ __forceinline__ void logits_epilogue(const SkinnyArgs& a, const float
     }
 }
 
-// AMX (with LNR): the row prologue of kind 3 -- the token comes from the previous step's vocabulary-head partials (an instantiation of
-// its own: in the common one the scan's registers cost the kind 1 / 2 prologues a spill)
-template <int K32, int EPI, bool FP8, bool LNR, bool AMX = false>
+template <int K32, int EPI, bool FP8, bool LNR>
 __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
     const int lane = threadIdx.x;
     const int frow = lane & 15, fq = lane >> 4;
@@ -115,42 +113,8 @@ __global__ __launch_bounds__(64) void skinny_full_kernel(SkinnyArgs a) {
             f32x4 v[NV], gv[NV], bev[NV];
             row_load_vec<NV>(gv, p.g, a.K, lane);                // gamma / beta: requested ahead of the row's own loads
             row_load_vec<NV>(bev, p.b, a.K, lane);
-            float s;
-            if constexpr (AMX) {
-                // the token of row m: arg-max over the previous step's head partials (order independent: max value, smallest index
-                // among equals), 8 pairs per lane and round trip; every workgroup computes it, workgroup 0 publishes it
-                float best = -INFINITY;
-                int bi = 0x7fffffff;
-                const size_t base = (size_t)m * p.am_ntiles;
-                for (int i0 = lane; i0 < p.am_ntiles; i0 += 64 * 8) {
-                    float v8[8];
-                    int j8[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int i = min(i0 + 64 * u, p.am_ntiles - 1);           // (past the end: the last tile again)
-                        v8[u] = p.am_val[base + i];
-                        j8[u] = p.am_idx[base + i];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (v8[u] > best || (v8[u] == best && j8[u] < bi)) { best = v8[u]; bi = j8[u]; }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float v2 = __shfl_xor(best, o);
-                    const int i2 = __shfl_xor(bi, o);
-                    if (v2 > best || (v2 == best && i2 < bi)) { best = v2; bi = i2; }
-                }
-                if (bi == 0x7fffffff) bi = 0;
-                if (blockIdx.x == 0 && lane == 0) {
-                    p.ids_w[(size_t)m * p.ld_ids] = bi;
-                    if (p.sep_cnt && bi == p.sep_id) atomicAdd(&p.sep_cnt[p.sep_step], 1);
-                }
-                s = row_load_embed_tok<NV>(v, (int64_t)bi, p.t0, p.word, p.pos, a.K, p.vocab, lane);
-            } else {
-                s = p.kind == 1 ? row_load_reduce<NV>(v, p.slabs, p.nslab, p.bias, p.resid, a.M, a.K, m, lane)
-                                : row_load_embed<NV>(v, p.ids, p.ld_ids, p.T, p.t0, p.word, p.pos, a.K, p.vocab, m, lane);
-            }
+            const float s = p.kind == 1 ? row_load_reduce<NV>(v, p.slabs, p.nslab, p.bias, p.resid, a.M, a.K, m, lane)
+                                        : row_load_embed<NV>(v, p.ids, p.ld_ids, p.T, p.t0, p.word, p.pos, a.K, p.vocab, m, lane);
             row_layernorm_v<NV>(v, s, lane, a.K, p.eps, gv, bev);
             row_store<NV>(v, lane, a.K, blockIdx.x == 0 ? p.xf + (size_t)m * a.K : nullptr, (bf16_t*)nullptr);
 #pragma unroll
@@ -462,9 +426,7 @@ hipError_t launch_full_rows(const SkinnyArgs& a, int epi, hipStream_t s) {
     const SkinnyArgs::RowPrologue& p = a.ln;
     if (!skinny_row_prologue_ok(a.M, a.K, a.wscale != nullptr) || !p.g || !p.b || !p.xf ||
         (p.kind == 1 && (!p.slabs || p.nslab <= 0 || !p.bias || !p.resid || p.resid == p.xf)) ||
-        (p.kind == 2 && (!p.ids || p.T <= 0 || !p.word || !p.pos)) ||
-        (p.kind == 3 && (!p.am_val || !p.am_idx || p.am_ntiles <= 0 || !p.ids_w || p.T != 1 || !p.word || !p.pos)) ||
-        (p.kind != 1 && p.kind != 2 && p.kind != 3))
+        (p.kind == 2 && (!p.ids || p.T <= 0 || !p.word || !p.pos)) || (p.kind != 1 && p.kind != 2))
         return hipErrorInvalidValue;
     const dim3 grid((a.N + 15) / 16);
     // many slabs (the fused FFN's 48): three waves per workgroup share the reduce (skinny_rows3_kernel)
@@ -473,11 +435,6 @@ hipError_t launch_full_rows(const SkinnyArgs& a, int epi, hipStream_t s) {
         if (epi == SK_BIAS_BF16) hipLaunchKernelGGL((skinny_rows3_kernel<K32, SK_BIAS_BF16>), grid3, dim3(192), 0, s, a);
         else if (epi == SK_BIAS_RELU_BF16) hipLaunchKernelGGL((skinny_rows3_kernel<K32, SK_BIAS_RELU_BF16>), grid3, dim3(192), 0, s, a);
         else return hipErrorInvalidValue;
-        return hipGetLastError();
-    }
-    if (p.kind == 3) {
-        if (epi != SK_BIAS_BF16) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16, false, true, true>), grid, dim3(64), 0, s, a);
         return hipGetLastError();
     }
     if (epi == SK_BIAS_BF16) hipLaunchKernelGGL((skinny_full_kernel<K32, SK_BIAS_BF16, false, true>), grid, dim3(64), 0, s, a);

@@ -103,7 +103,7 @@ def test_speed_switches_are_process_wide_and_documented():
     previous value and restores; an unknown key is refused.  The product kernels behind keys 10 and 11 must be in the code object."""
     lib = _lib.load()
     hdr = open(os.path.join(ROOT, "include", "gitcap.h")).read()
-    for key in range(13):
+    for key in range(12):
         if key in (2, 3, 6):                 # thresholds / a poll count, not on-off switches
             old = lib.gitcap_dbg_config(key, 1)
             assert old >= 0 and lib.gitcap_dbg_config(key, old) == 1
@@ -115,6 +115,6 @@ def test_speed_switches_are_process_wide_and_documented():
         assert old in (0, 1), key
         assert lib.gitcap_dbg_config(key, old) == 0 and lib.gitcap_dbg_config(key, old) == old
         assert re.search(r"\b%d:" % key, hdr) or ("key %d" % key) in hdr, f"include/gitcap.h does not document key {key}"
-    assert lib.gitcap_dbg_config(13, 0) < 0
+    assert lib.gitcap_dbg_config(12, 0) < 0
     blob = open(_lib.LIB_PATH, "rb").read()
     assert b"skinny_head_kernel" in blob and b"skinny_rows3_kernel" in blob
