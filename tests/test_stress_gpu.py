@@ -10,10 +10,17 @@
       settable (gitcap_set_fp8_scale) -- on the stress weights the mode either passes at a calibrated scale or reports
       saturations, never neither.
 
-Tolerances.  The plain-weight rules of tests/test_parity_gpu.py are 0.08 against the bf16-emulating oracle and 0.20 against
-fp32 on logits of std ~4, where the emulating oracle itself sits 0.10 from fp32: i.e. 0.8 x and 2 x the distance the bf16
-rounding points alone create.  Outlier channels amplify that distance (a bf16 rounding step of a value of 60 is 0.25), so
-here the same two factors are applied to the distance MEASURED on the input at hand, never below the plain-weight numbers.
+Tolerances (end to end; the stage-by-stage checks on the device's own inputs, with FIXED tolerances, are
+tests/test_stress_layers_gpu.py -- they are what localises a kernel error; the numbers here bound what the network makes of it).
+The plain-weight rules of tests/test_parity_gpu.py are 0.08 against the bf16-emulating oracle and 0.20 against fp32 on logits of
+std ~4, where the emulating oracle itself sits 0.10 from fp32.  Outlier channels amplify that distance (a bf16 rounding step of a
+value of 60 is 0.25) and two legitimate roundings of an ill-conditioned row decorrelate, so here (`_tols`, `_check_logits`):
+  * max rule: |device - emulating oracle| <= 1.5 x and |device - fp32| <= 2 x the distance d = max |emulating - fp32| measured on
+    the input at hand, never below the plain-weight numbers;
+  * rms rule: the device no further (rms) from either oracle than 1.5 x the emulating oracle's own rms distance from fp32;
+  * PINS (round 6): on the fixed fixtures the max and rms device-vs-emulating distances are additionally held to their
+    measured values + headroom (`PINS`), so that a regression of the size of the bf16 emulation error itself cannot hide behind a
+    tolerance derived from the same input; the near-tie gate of the token checks is capped at an absolute 2.0 logits.
 """
 import os
 
@@ -46,6 +53,12 @@ def _rms(x):
     return float(x.double().pow(2).mean().sqrt())
 
 
+# measured (GPUTEST r05 / r06 logs: max, rms of device - emulating oracle) -> allowed (about 1.4 x)
+PINS = {"tiny stress": (0.45, 0.050), "base stress": (1.50, 0.135), "stress T=39": (1.65, 0.130), "plain T=39": (0.15, 0.027),
+        "GIT-large stress": (1.50, 0.135)}
+NEAR_TIE_CAP = 2.0
+
+
 def _check_logits(tag, lg, l_e, l_f):
     """max rule: |device - emulating oracle| <= 1.5 x and |device - fp32| <= 2 x the distance the bf16 rounding points alone create
     on this input (never below the plain-weight tolerances); rms rule: over all logits the device is no further from the
@@ -59,7 +72,9 @@ def _check_logits(tag, lg, l_e, l_f):
           f"rms emul - fp32 {r0:.4f}, device - emul {re:.4f}, device - fp32 {rf:.4f}; logit std {float(l_f.std()):.2f}")
     assert de < tol_e and df < tol_f
     assert re < 1.5 * r0 + 0.004 and rf < 1.5 * r0 + 0.004
-    return tol_e, tol_f
+    if tag in PINS:
+        assert de < PINS[tag][0] and re < PINS[tag][1], (tag, de, re, PINS[tag])
+    return min(tol_e, NEAR_TIE_CAP / 2), tol_f
 
 
 def _margin_gated(dev_ids, logits, near_tie):
