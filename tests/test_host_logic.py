@@ -151,3 +151,22 @@ def test_fp8_weight_quantisation_is_exact_in_bf16_and_close():
         # idempotent: quantising again changes nothing
     q2 = W.quantize_weights_fp8(q)
     assert all(np.array_equal(q[k], q2[k]) for k in q)
+
+
+def test_host_copy_is_a_memcpy_for_every_size():
+    """gitcap_host_copy (the staging copy of host-fed submissions; no device work): plain memcpy semantics at every size -- below the
+    4 MiB per-thread piece (one thread), across piece boundaries and with a ragged tail -- and argument checks."""
+    import ctypes
+    import torch
+    from gitcap import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    for n in (0, 1, 4095, 4096, (4 << 20) - 1, (4 << 20) + 1, 9 * (1 << 20) + 123, 40 * (1 << 20) + 7):
+        src = torch.randint(0, 256, (max(n, 1) + 64,), dtype=torch.uint8, generator=g)
+        dst = torch.zeros_like(src)
+        assert lib.gitcap_host_copy(ctypes.c_void_p(dst.data_ptr() + 32), ctypes.c_void_p(src.data_ptr() + 32), n) == 0
+        assert torch.equal(dst[32:32 + n], src[32:32 + n]), n
+        assert int(dst[:32].sum()) == 0 and int(dst[32 + n:].sum()) == 0, n       # nothing outside [32, 32 + n)
+    assert lib.gitcap_host_copy(None, None, 0) == 0
+    assert lib.gitcap_host_copy(None, ctypes.c_void_p(src.data_ptr()), 8) == -1
+    assert lib.gitcap_host_copy(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), -1) == -1

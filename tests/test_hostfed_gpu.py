@@ -161,3 +161,34 @@ def test_sync_call_between_submit_and_result_with_exchange_failure(captioner_cls
         assert not m._undelivered
     finally:
         lib.gitcap_dbg_config(6, old)
+
+
+def test_refused_submissions_leave_the_pipeline_usable(captioner_cls):
+    """an entry point that refuses a submission -- bad frame sizes, a batch beyond max_batch -- between good ones: the
+    refusal is reported, no ticket is consumed, the submissions around it deliver the synchronous results, and the slot sequence goes on."""
+    import ctypes
+    from gitcap import _lib
+    lib = _lib.load()
+    cfg = git_tiny(2)
+    m = captioner_cls(cfg, synthetic_weights(cfg, 0), max_batch=2, max_frames=2, max_text_len=10, stop="never")
+    x = make_frames(2, 2, cfg.image_size, 11).cuda()
+    cam = _camera(2, 2, 80, 96, 4).cuda()
+    want_x, want_c = m.greedy_decode(x, max_len=9).clone(), m.greedy_decode(cam, max_len=9).clone()
+    ids = torch.empty((4, 10), dtype=torch.int64, device="cuda")
+    steps = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    tk = ctypes.c_int(-7)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    futs = [m.greedy_decode_async(x, max_len=9), m.greedy_decode_async(cam, max_len=9)]
+    assert lib.gitcap_greedy_raw_submit(m._handle, p(cam), 2, 2, 0, 96, 9, 0, p(ids), p(steps), st, ctypes.byref(tk)) == -1      # H = 0
+    assert b"raw frames" in lib.gitcap_last_error(m._handle) and tk.value == -7
+    assert lib.gitcap_greedy_raw_submit(m._handle, p(cam), 4, 2, 80, 96, 9, 0, p(ids), p(steps), st, ctypes.byref(tk)) == -1     # B > max_batch
+    assert lib.gitcap_greedy_submit(m._handle, p(x), 2, 3, 9, 0, p(ids), p(steps), st, ctypes.byref(tk)) == -1                    # F > max_frames
+    assert lib.gitcap_greedy_raw_submit(m._handle, None, 2, 2, 80, 96, 9, 0, p(ids), p(steps), st, ctypes.byref(tk)) == -1
+    assert tk.value == -7
+    futs += [m.greedy_decode_async(cam.cpu(), max_len=9), m.greedy_decode_async(x.cpu(), max_len=9), m.greedy_decode_async(x, max_len=9)]
+    got = [f.result() for f in futs]
+    assert torch.equal(got[0], want_x) and torch.equal(got[1], want_c) and torch.equal(got[2], want_c.cpu())
+    assert torch.equal(got[3], want_x.cpu()) and torch.equal(got[4], want_x)
+    assert torch.equal(m.greedy_decode(x, max_len=9), want_x)
+    m.poll_errors()

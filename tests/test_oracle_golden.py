@@ -149,3 +149,35 @@ def test_base_oracle_matches_hf_stress(golden_dir):
     margin = g["greedy_top_vals"][..., 0] - g["greedy_top_vals"][..., 1]
     assert np.array_equal(logits.argmax(-1).numpy()[margin > 2e-2], ids[:, 1:].numpy()[margin > 2e-2])
     assert len(set(ids[0].tolist())) > 10                              # varied captions, not one repeated token
+
+
+def test_oracle_e4m3_v_mode_is_self_consistent():
+    """GitOracle(emulate_fp8_v=True) (the device's kv_cache="v_e4m3"): only the TEXT rows see the quantised V of the image keys -- the
+    visual features, the projected memory and the image rows' own layers are those of the bf16 oracle; the split teacher-forced pass, the
+    cached greedy loop and the single-layer helper agree with each other; the quantisation is e4m3 x 2^k per (token, head) and idempotent."""
+    from oracle.git_oracle import _q8
+    cfg = git_tiny(2)
+    w = synthetic_weights(cfg, 0)
+    fr = make_frames(2, 2, cfg.image_size, 7)
+    a, b = GitOracle(cfg, w, emulate_bf16=True), GitOracle(cfg, w, emulate_bf16=True, emulate_fp8_v=True)
+    ids = torch.tensor([[101, 5, 9, 7, 3], [101, 77, 3, 2, 11]])
+    with torch.no_grad():
+        va, ma = a.forward_image_enc(fr)
+        vb, mb = b.forward_image_enc(fr)
+        assert torch.equal(va, vb) and torch.equal(ma, mb)
+        ka, kb = a.image_kv(ma), b.image_kv(mb)
+        for (k0, v0), (k1, v1) in zip(ka, kb):
+            assert torch.equal(k0, k1) and torch.equal(v1, _q8(v0)) and torch.equal(_q8(v1), v1)
+            assert not torch.equal(v0, v1) and float((v1 - v0).abs().max()) <= float(v0.abs().max()) / 16.0
+        la, lb = a.decoder_full(ma, ids), b.decoder_full(mb, ids)
+        assert 0.0 < float((la - lb).abs().max()) < 0.5
+        # cached loop == teacher-forced pass on its own tokens (fp32 arithmetic with only V quantised: no bf16 rounding to flip);
+        # single-layer helper == the layer inside the split pass
+        c = GitOracle(cfg, w, emulate_fp8_v=True)
+        out, lg = c.greedy_decode(fr, 5, stop="never", return_logits=True)
+        assert float((c.decoder_full(c.forward_image_enc(fr)[1], out[:, :-1]) - lg).abs().max()) < 1e-4
+        S = mb.shape[1]
+        x = torch.cat([mb, b.embed_text(ids)], dim=1)
+        kt, vt = b._kv(0, x[:, S:])
+        ref = b._dec_layer(0, x[:, S:], torch.cat([kb[0][0], kt], 2), torch.cat([kb[0][1], vt], 2), S + torch.arange(ids.shape[1]) + 1)
+        assert float((b.dec_layer_text(0, x, S) - ref).abs().max()) < 1e-5
