@@ -114,7 +114,7 @@ class _StagingRing:
         """Copy the CPU tensors `parts` (same trailing shape; concatenated along dim 0) to the device.  stream=None: the
         pipelined form (next ring entry, the ring's copy stream = the caller's current stream by default); else the synchronous
         form on that stream, in the entry of its own.
-        Returns (device tensor, entry)."""
+        Returns (device tensor, entry, the stream the copy was enqueued on)."""
         sync = stream is not None
         e = self.entries[-1] if sync else self.entries[self.n % self.DEPTH]
         if not sync:
