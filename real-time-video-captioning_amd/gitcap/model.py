@@ -77,7 +77,8 @@ class _StagingRing:
 
     Pageable sources are copied into the pinned buffer by gitcap_host_copy (up to 8 threads, sized to the CPU quota: ATen's own
     parallel copy sizes its pool to the whole machine and takes 20 ms per batch under a 16-core quota); page-locked sources
-    (DataLoader(pin_memory=True), a capture ring) are copied from where they are.
+    (DataLoader(pin_memory=True), a capture ring) are copied from where they are -- asynchronously: the caller must leave such a
+    buffer alone until the submission's result() (the usual contract of a non_blocking copy; the future keeps a reference).
 
     Depth = the library's four slots.  An entry is reused four submissions later; before its device buffer is overwritten the
     copy's stream waits for the submission that read it (its `done_ev`, or the library's own wait while it is still in flight),
